@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures in this directory from the REAL reference.
+
+Run once in the build container (needs /root/reference; never runs on the GPU
+box, never imported by tests):
+
+    python tests/golden/generate_golden.py
+
+How the reference is executed: its model files import three symbols from
+torchvision.ops, which is not installed here, so `torchvision`,
+`torchvision.ops` and `torchvision.models` are pre-seeded in sys.modules with
+tiny stand-in modules whose box_iou / box_convert / batched_nms are the CPU
+oracle's restatements (oracle/boxops_oracle.py).  Everything else -- anchor
+tables, the whole of loss() and pre_predict(), Predictor.run -- is the
+reference's own unmodified code, imported from /root/reference/src.  Model
+objects are built "bare" (no backbone): cls.__new__ + nn.Module.__init__, then
+the anchor-table attributes are filled by the reference's own generators.
+
+loss() returns only scalars, so its Step-1 results (target_locs,
+target_labels, matched_bbox_ids ...) are captured from the function's local
+variables with sys.setprofile at the moment loss() returns.
+
+Only data is written here (inputs, expected outputs, hashes): no reference
+source text.
+"""
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF_SRC = '/root/reference/src'
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+
+from oracle import boxops_oracle as O  # noqa: E402
+
+# ---- stand-ins for the missing third-party modules ---------------------------
+tv = types.ModuleType('torchvision')
+tv_ops = types.ModuleType('torchvision.ops')
+tv_models = types.ModuleType('torchvision.models')
+tv_ops.box_iou, tv_ops.box_convert, tv_ops.batched_nms = O.box_iou, O.box_convert, O.batched_nms
+tv.ops, tv.models = tv_ops, tv_models
+sys.modules.update({'torchvision': tv, 'torchvision.ops': tv_ops, 'torchvision.models': tv_models})
+sns = types.ModuleType('seaborn')
+sys.modules['seaborn'] = sns
+sys.path.insert(0, REF_SRC)
+
+from models.ssd300 import SSD300  # noqa: E402
+from models.ssd512 import SSD512  # noqa: E402
+from models.retinanet import RetinaNet  # noqa: E402
+from models.fcos import FCOS  # noqa: E402
+from models.yolov3 import YoloV3  # noqa: E402
+import importlib.util  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location('ref_predictor', os.path.join(REF_SRC, 'utilities', 'predictor.py'))
+ref_predictor = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(ref_predictor)
+
+
+def bare(cls, nc):
+    m = cls.__new__(cls)
+    nn.Module.__init__(m)
+    m.nc = nc
+    return m
+
+
+def sha(t):
+    return hashlib.sha256(np.ascontiguousarray(t.numpy()).tobytes()).hexdigest()
+
+
+def capture_loss_locals(model, outputs, gt_bboxes, gt_labels, names, **kw):
+    """Run the reference loss() and return the requested local variables as they
+    stand when loss() returns (or raises)."""
+    grabbed = {}
+    code = type(model).loss.__code__
+
+    def prof(frame, event, arg):
+        if event == 'return' and frame.f_code is code:
+            for n in names:
+                if n in frame.f_locals:
+                    v = frame.f_locals[n]
+                    grabbed[n] = v.clone() if torch.is_tensor(v) else v
+
+    sys.setprofile(prof)
+    try:
+        try:
+            model.loss(outputs, gt_bboxes, gt_labels, **kw)
+        except Exception as e:  # Steps 2-5 may fail on odd inputs; Step 1 locals are still there
+            grabbed['_exception'] = repr(e)
+    finally:
+        sys.setprofile(None)
+    return grabbed
+
+
+def pack_gt(gt_bboxes, gt_labels):
+    off = np.zeros(len(gt_bboxes) + 1, dtype=np.int32)
+    for i, b in enumerate(gt_bboxes):
+        off[i + 1] = off[i] + b.shape[0]
+    return (torch.cat(gt_bboxes).numpy().astype(np.float32), torch.cat(gt_labels).numpy().astype(np.int64), off)
+
+
+def head_outputs(seed, B, P, C, sparse_images=(), extra=False, bg_bias=8.0, obj_bias=-6.0, yolo=False, loc_bias=0.0):
+    g = torch.Generator().manual_seed(seed)
+    locs = torch.randn(B, P, 4, generator=g) + loc_bias
+    confs = torch.randn(B, P, C, generator=g)
+    ext = torch.randn(B, P, generator=g) if extra else None
+    for b in sparse_images:
+        if yolo:
+            ext[b] += obj_bias
+        else:
+            confs[b, :, 0] += bg_bias
+    return locs, confs, ext
+
+
+def assign_case(name, model, anchors_hash, gt_bboxes, gt_labels, nc, C, out, big=False, fcos=False, **kw):
+    """One loss() call per image (B=1) so that the per-image matched ids are visible."""
+    P = {'ssd': lambda: model.dboxes, 'fcos': lambda: model.points}.get(
+        'fcos' if fcos else ('ssd' if hasattr(model, 'dboxes') else 'x'), lambda: model.pboxes)().shape[0]
+    locs_all, labels_all, matched_all, cents_all = [], [], [], []
+    for i in range(len(gt_bboxes)):
+        g = torch.Generator().manual_seed(77 + i)
+        outs = [torch.randn(1, P, 4, generator=g)]
+        if isinstance(model, YoloV3):
+            outs += [torch.randn(1, P, generator=g), torch.randn(1, P, C, generator=g)]
+        elif fcos:
+            outs += [torch.randn(1, P, C, generator=g), torch.randn(1, P, generator=g)]
+        else:
+            outs += [torch.randn(1, P, C, generator=g)]
+        got = capture_loss_locals(model, tuple(outs), [gt_bboxes[i].clone()], [gt_labels[i].clone()],
+                                  ['target_locs', 'target_labels', 'matched_bbox_ids', 'target_cents'], **kw)
+        locs_all.append(got['target_locs'][0].cpu())
+        labels_all.append(got['target_labels'][0].cpu())
+        matched_all.append(got['matched_bbox_ids'].cpu())
+        if fcos:
+            cents_all.append(got['target_cents'][0].cpu())
+    locs, labels, matched = torch.stack(locs_all), torch.stack(labels_all), torch.stack(matched_all)
+    gb, gl, off = pack_gt(gt_bboxes, gt_labels)
+    d = dict(gt_boxes=gb, gt_labels=gl, gt_offsets=off, anchors_sha256=np.array(anchors_hash),
+             labels=labels.numpy().astype(np.int16), matched=matched.numpy().astype(np.int16),
+             locs_sha256=np.array(sha(locs)))
+    if fcos:
+        cents = torch.stack(cents_all)
+        d['cents_sha256'] = np.array(sha(cents))
+    if big:
+        # positives + a regular subsample, to keep the file small
+        sel = ((labels != 0) | (torch.arange(P)[None, :] % 97 == 0))
+        bi, pi = torch.nonzero(sel, as_tuple=True)
+        d.update(sub_b=bi.numpy().astype(np.int32), sub_p=pi.numpy().astype(np.int32),
+                 sub_locs=locs[bi, pi].numpy())
+        if fcos:
+            d['sub_cents'] = cents[bi, pi].numpy()
+    else:
+        d['locs'] = locs.numpy()
+        if fcos:
+            d['cents'] = cents.numpy()
+    for k, v in kw.items():
+        d['kw_' + k] = np.array(v, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, f'assign_{name}.npz'), **d)
+    out[f'assign_{name}'] = dict(B=len(gt_bboxes), P=int(P), positives=int((labels > 0).sum()),
+                                 ignored=int((labels < 0).sum()))
+
+
+def check_no_boundary_tie(confs, class_begin, conf_thresh, top_k):
+    """Fixtures must not depend on the (unspecified) tie order of the reference's
+    non-stable argsort at the top-k boundary."""
+    for b in range(confs.shape[0]):
+        for c in range(class_begin, confs.shape[2]):
+            col = confs[b, :, c]
+            srt = col.sort(descending=True).values
+            if srt.numel() > top_k and srt[top_k - 1] == srt[top_k] and srt[top_k] > conf_thresh:
+                raise AssertionError(f'boundary tie image {b} class {c}')
+
+
+def predict_case(name, run_pre_predict, anchors_hash, spec, metas, out, activated, class_begin,
+                 conf_thresh, top_k, store_inputs=None):
+    bboxes, scores, class_ids = run_pre_predict()
+    check_no_boundary_tie(activated, class_begin, conf_thresh, top_k)
+    counts = np.array([b.shape[0] for b in bboxes], dtype=np.int32)
+    pred = ref_predictor.Predictor(iou_thresh=0.45)
+    result = pred.run(metas, bboxes, scores, class_ids)
+    keeps = []
+    for b, s, c in zip(bboxes, scores, class_ids):
+        k_v = O.batched_nms(b, s, c, 0.45)
+        k_t = O.batched_nms_coordinate_trick(b, s, c, 0.45)
+        if not torch.equal(k_v, k_t):
+            raise AssertionError(f'{name}: per-class and coordinate-trick NMS disagree; pick another seed')
+        keeps.append(k_v)
+    keep_counts = np.array([k.numel() for k in keeps], dtype=np.int32)
+    assert int(keep_counts.sum()) == len(result)
+    rows_ids = np.array([[r['image_id'], r['category_id']] for r in result], dtype=np.int64).reshape(-1, 2)
+    rows_vals = np.array([r['bbox'] + [r['score']] for r in result], dtype=np.float64).reshape(-1, 5)
+    d = dict(spec=np.array(json.dumps(spec)), anchors_sha256=np.array(anchors_hash),
+             counts=counts, bboxes=torch.cat(bboxes).numpy(), scores=torch.cat(scores).numpy(),
+             class_ids=torch.cat(class_ids).numpy().astype(np.int16),
+             keep_counts=keep_counts, keeps=torch.cat(keeps).numpy().astype(np.int32),
+             rows_ids=rows_ids, rows_vals=rows_vals,
+             metas=np.array(json.dumps(metas)))
+    if store_inputs:
+        d.update({k: v.numpy() for k, v in store_inputs.items()})
+    np.savez_compressed(os.path.join(HERE, f'predict_{name}.npz'), **d)
+    out[f'predict_{name}'] = dict(counts=counts.tolist(), keep_counts=keep_counts.tolist())
+
+
+def main():
+    torch.manual_seed(0)
+    manifest = {'torch': torch.__version__, 'notes': {}}
+
+    # ---------------- anchor tables ----------------
+    ssd300 = bare(SSD300, 21); ssd300.dboxes = ssd300._get_default_boxes()
+    ssd512 = bare(SSD512, 21); ssd512.dboxes = ssd512._get_default_boxes()
+    fk512, fk800, fksmall = [64, 32, 16, 8, 4], [100, 50, 25, 13, 7], [8, 4, 2, 1, 1]
+    ret512 = bare(RetinaNet, 21); ret512.pboxes = ret512._get_prior_boxes(fk512)
+    ret800 = bare(RetinaNet, 81); ret800.pboxes = ret800._get_prior_boxes(fk800)
+    retsm = bare(RetinaNet, 5); retsm.pboxes = retsm._get_prior_boxes(fksmall)
+    fcos512 = bare(FCOS, 21); fcos512.points = fcos512._get_points(fk512); fcos512.regress_ranges = fcos512._get_regress_ranges(fk512)
+    fcos800 = bare(FCOS, 81); fcos800.points = fcos800._get_points(fk800); fcos800.regress_ranges = fcos800._get_regress_ranges(fk800)
+    yolo = bare(YoloV3, 20); yolo.pboxes = yolo._get_prior_boxes()
+    tables = {
+        'ssd300_dboxes': ssd300.dboxes, 'ssd512_dboxes': ssd512.dboxes,
+        'retinanet512_pboxes': ret512.pboxes, 'retinanet800_pboxes': ret800.pboxes,
+        'retinanet_small_pboxes': retsm.pboxes,
+        'fcos512_points': fcos512.points, 'fcos512_ranges': fcos512.regress_ranges,
+        'fcos800_points': fcos800.points, 'fcos800_ranges': fcos800.regress_ranges,
+        'yolov3_pboxes': yolo.pboxes,
+    }
+    manifest['anchor_tables'] = {k: dict(shape=list(v.shape), dtype=str(v.dtype), sha256=sha(v),
+                                         first=v[0].tolist(), last=v[-1].tolist()) for k, v in tables.items()}
+    H = {k: v['sha256'] for k, v in manifest['anchor_tables'].items()}
+
+    # ---------------- target assignment ----------------
+    out = {}
+    # hand-made SSD300 cases: exact default-box hit, two GTs sharing one best box,
+    # a tiny GT whose best IoU is < 0.5 (forced match keeps the arg-max GT's label), a box leaving the image
+    d = ssd300.dboxes
+    hand_b = [
+        torch.stack([d[4000], d[4000] * torch.tensor([1.0, 1.0, 0.9, 0.9]), torch.tensor([0.5, 0.5, 0.01, 0.01])]),
+        torch.tensor([[0.95, 0.95, 0.3, 0.3], [0.2, 0.3, 0.4, 0.2]]),
+        torch.tensor([[0.5, 0.5, 1.0, 1.0]]),
+    ]
+    hand_l = [torch.tensor([3, 7, 20]), torch.tensor([1, 2]), torch.tensor([15])]
+    assign_case('ssd300_hand', ssd300, H['ssd300_dboxes'], hand_b, hand_l, 21, 21, out)
+    gts = [O.synth_gt(i, 20, False) for i in (0, 5, 15)]
+    assign_case('ssd300_rand', ssd300, H['ssd300_dboxes'], [g[0] for g in gts], [g[1] for g in gts], 21, 21, out)
+    gts = [O.synth_gt(i, 20, False) for i in (7,)]
+    assign_case('ssd512_rand', ssd512, H['ssd512_dboxes'], [g[0] for g in gts], [g[1] for g in gts], 21, 21, out, big=True)
+    gts = [O.synth_gt(i, 4, False) for i in (2, 9)]
+    assign_case('retinanet_small', retsm, H['retinanet_small_pboxes'], [g[0] for g in gts], [g[1] for g in gts], 5, 5, out)
+    gts = [O.synth_gt(i, 20, True) for i in (3, 40)]
+    assign_case('retinanet512_rand', ret512, H['retinanet512_pboxes'], [g[0] for g in gts], [g[1] for g in gts], 21, 21, out, big=True)
+    gts = [O.synth_gt(i, 80, True) for i in (63,)]
+    assign_case('retinanet800_rand', ret800, H['retinanet800_pboxes'], [g[0] for g in gts], [g[1] for g in gts], 81, 81, out, big=True)
+    gts = [O.synth_gt(i, 20, False, fmt='xywh') for i in (1, 6, 12)]
+    assign_case('yolov3_rand', yolo, H['yolov3_pboxes'], [g[0] for g in gts], [g[1] for g in gts], 20, 20, out)
+    gts = [O.synth_gt(i, 20, False, scale=512.0) for i in (0, 4, 11)]
+    assign_case('fcos512_rand', fcos512, H['fcos512_points'], [g[0] for g in gts], [g[1] for g in gts], 21, 21, out, fcos=True)
+    gts = [O.synth_gt(i, 80, True, scale=512.0) for i in (30,)]
+    assign_case('fcos800_rand', fcos800, H['fcos800_points'], [g[0] for g in gts], [g[1] for g in gts], 81, 81, out, big=True, fcos=True)
+    # non-default thresholds
+    gts = [O.synth_gt(i, 20, False) for i in (9,)]
+    assign_case('ssd300_thr035', ssd300, H['ssd300_dboxes'], [g[0] for g in gts], [g[1] for g in gts], 21, 21, out,
+                big=True, iou_thresh=0.35)
+
+    # ---------------- pre_predict + Predictor.run ----------------
+    metas2 = [{'image_id': 11, 'height': 375, 'width': 500}, {'image_id': 42, 'height': 480, 'width': 640}]
+
+    # small RetinaNet with explicit inputs
+    locs, confs, _ = head_outputs(5, 2, retsm.pboxes.shape[0], 5, sparse_images=(1,), bg_bias=3.0)
+    spec = dict(family='retinanet', f_k=fksmall, B=2, C=5, seed=5, sparse_images=[1], bg_bias=3.0, conf_thresh=0.05, top_k=20)
+    predict_case('retinanet_small', lambda: retsm.pre_predict((locs.clone(), confs.clone()), conf_thresh=0.05, top_k=20),
+                 H['retinanet_small_pboxes'], spec, metas2, out, torch.softmax(confs, -1), 1, 0.05, 20,
+                 store_inputs=dict(out_locs=locs, out_confs=confs))
+
+    locs, confs, _ = head_outputs(2000, 2, 8732, 21, sparse_images=(1,))
+    spec = dict(family='ssd300', B=2, C=21, seed=2000, sparse_images=[1], bg_bias=8.0, conf_thresh=0.01, top_k=200,
+                inputs_sha256=[sha(locs), sha(confs)])
+    predict_case('ssd300', lambda: ssd300.pre_predict((locs.clone(), confs.clone())),
+                 H['ssd300_dboxes'], spec, metas2, out, torch.softmax(confs, -1), 1, 0.01, 200)
+
+    locs, confs, _ = head_outputs(2001, 1, 49104, 21)
+    spec = dict(family='retinanet', f_k=fk512, B=1, C=21, seed=2001, sparse_images=[], bg_bias=8.0, conf_thresh=0.01, top_k=200,
+                inputs_sha256=[sha(locs), sha(confs)])
+    predict_case('retinanet512', lambda: ret512.pre_predict((locs.clone(), confs.clone())),
+                 H['retinanet512_pboxes'], spec, metas2[:1], out, torch.softmax(confs, -1), 1, 0.01, 200)
+
+    locs, confs, cents = head_outputs(2002, 2, 5456, 21, sparse_images=(1,), extra=True, bg_bias=2.0, loc_bias=3.0)
+    spec = dict(family='fcos', f_k=fk512, B=2, C=21, seed=2002, sparse_images=[1], bg_bias=2.0, loc_bias=3.0, conf_thresh=0.01, top_k=200,
+                inputs_sha256=[sha(locs), sha(confs), sha(cents)])
+    act = torch.softmax(confs, -1) * cents.sigmoid()[..., None]
+    predict_case('fcos512', lambda: fcos512.pre_predict((locs.clone(), confs.clone(), cents.clone())),
+                 H['fcos512_points'], spec, metas2, out, act, 1, 0.01, 200)
+
+    # YoloV3.pre_predict has no runnable reference behaviour
+    locs, confs, objs = head_outputs(2003, 1, 10647, 20, extra=True, yolo=True)
+    try:
+        yolo.pre_predict((locs.clone(), objs.clone(), confs.clone()))
+        manifest['notes']['yolov3_pre_predict'] = 'ran (unexpected)'
+    except TypeError as e:
+        manifest['notes']['yolov3_pre_predict'] = f'TypeError: {e}'
+
+    manifest['cases'] = out
+    with open(os.path.join(HERE, 'manifest.json'), 'w') as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    print(json.dumps(manifest['cases'], indent=1))
+    print(manifest['notes'])
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,73 @@
+"""Shared helpers for the tests: golden-fixture loading and input regeneration."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def sha(t: torch.Tensor) -> str:
+    return hashlib.sha256(np.ascontiguousarray(t.detach().cpu().numpy()).tobytes()).hexdigest()
+
+
+def manifest():
+    with open(os.path.join(GOLDEN, 'manifest.json')) as f:
+        return json.load(f)
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + '.npz'))
+
+
+def unpack_gt(z):
+    off = z['gt_offsets']
+    gb, gl = torch.from_numpy(z['gt_boxes']), torch.from_numpy(z['gt_labels'])
+    return ([gb[off[i]:off[i + 1]].clone() for i in range(len(off) - 1)],
+            [gl[off[i]:off[i + 1]].clone() for i in range(len(off) - 1)])
+
+
+def head_outputs(seed, B, P, C, sparse_images=(), extra=False, bg_bias=8.0, obj_bias=-6.0, yolo=False, loc_bias=0.0):
+    """Seeded synthetic head outputs; the same recipe the golden generator used."""
+    g = torch.Generator().manual_seed(seed)
+    locs = torch.randn(B, P, 4, generator=g) + loc_bias
+    confs = torch.randn(B, P, C, generator=g)
+    ext = torch.randn(B, P, generator=g) if extra else None
+    for b in sparse_images:
+        if yolo:
+            ext[b] += obj_bias
+        else:
+            confs[b, :, 0] += bg_bias
+    return locs, confs, ext
+
+
+def predict_inputs(z, P):
+    """Rebuild (out_locs, out_confs, extra) of a predict_* fixture, checking the
+    recorded input hashes when the inputs are seed-generated."""
+    spec = json.loads(str(z['spec']))
+    if 'out_locs' in z.files:
+        return spec, torch.from_numpy(z['out_locs']), torch.from_numpy(z['out_confs']), None
+    locs, confs, ext = head_outputs(spec['seed'], spec['B'], P, spec['C'], tuple(spec['sparse_images']),
+                                    extra=spec['family'] in ('fcos',), bg_bias=spec['bg_bias'],
+                                    loc_bias=spec.get('loc_bias', 0.0))
+    hashes = [sha(locs), sha(confs)] + ([sha(ext)] if ext is not None else [])
+    assert hashes == spec['inputs_sha256'], 'seeded inputs differ from the ones the fixture was generated with'
+    return spec, locs, confs, ext
+
+
+def split(t, counts):
+    out, o = [], 0
+    for c in counts:
+        out.append(t[o:o + int(c)])
+        o += int(c)
+    return out
+
+
+def rel_close(a: torch.Tensor, b: torch.Tensor, rtol=1e-5, atol=1e-6):
+    """|a-b| <= atol + rtol*|b| elementwise, NaN == NaN."""
+    a, b = a.double(), b.double()
+    both_nan = a.isnan() & b.isnan()
+    ok = ((a - b).abs() <= atol + rtol * b.abs()) | both_nan | (a == b)
+    return bool(ok.all())

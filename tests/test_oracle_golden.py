@@ -1,0 +1,120 @@
+"""CPU: the oracle restatement reproduces what the real reference produced
+(fixtures in tests/golden, made by tests/golden/generate_golden.py)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load, manifest, predict_inputs, sha, split, unpack_gt
+
+
+def tables(O):
+    fk512, fk800, fksm = [64, 32, 16, 8, 4], [100, 50, 25, 13, 7], [8, 4, 2, 1, 1]
+    return {
+        'ssd300_dboxes': O.ssd300_default_boxes, 'ssd512_dboxes': O.ssd512_default_boxes,
+        'retinanet512_pboxes': lambda: O.retinanet_prior_boxes(fk512),
+        'retinanet800_pboxes': lambda: O.retinanet_prior_boxes(fk800),
+        'retinanet_small_pboxes': lambda: O.retinanet_prior_boxes(fksm),
+        'fcos512_points': lambda: O.fcos_points(fk512), 'fcos512_ranges': lambda: O.fcos_regress_ranges(fk512),
+        'fcos800_points': lambda: O.fcos_points(fk800), 'fcos800_ranges': lambda: O.fcos_regress_ranges(fk800),
+        'yolov3_pboxes': O.yolov3_prior_boxes,
+    }
+
+
+def test_anchor_tables_match_reference_hashes(oracle):
+    m = manifest()['anchor_tables']
+    for name, fn in tables(oracle).items():
+        t = fn()
+        assert list(t.shape) == m[name]['shape'], name
+        assert t.dtype == torch.float32
+        assert sha(t) == m[name]['sha256'], name
+
+
+ASSIGN = [
+    ('ssd300_hand', 'ssd', 'ssd300_dboxes'), ('ssd300_rand', 'ssd', 'ssd300_dboxes'),
+    ('ssd300_thr035', 'ssd', 'ssd300_dboxes'), ('ssd512_rand', 'ssd', 'ssd512_dboxes'),
+    ('retinanet_small', 'retina', 'retinanet_small_pboxes'), ('retinanet512_rand', 'retina', 'retinanet512_pboxes'),
+    ('retinanet800_rand', 'retina', 'retinanet800_pboxes'), ('yolov3_rand', 'yolo', 'yolov3_pboxes'),
+    ('fcos512_rand', 'fcos', 'fcos512_points'), ('fcos800_rand', 'fcos', 'fcos800_points'),
+]
+
+
+@pytest.mark.parametrize('name,family,table', ASSIGN)
+def test_assign_matches_reference(oracle, name, family, table):
+    O = oracle
+    z = load('assign_' + name)
+    gb, gl = unpack_gt(z)
+    anchors = tables(O)[table]()
+    assert sha(anchors) == str(z['anchors_sha256'])
+    cents = None
+    if family == 'ssd':
+        kw = {'iou_thresh': float(z['kw_iou_thresh'])} if 'kw_iou_thresh' in z.files else {}
+        locs, labels, matched = O.assign_ssd(anchors, gb, gl, **kw)
+    elif family == 'retina':
+        locs, labels, matched = O.assign_retinanet(anchors, gb, gl)
+    elif family == 'yolo':
+        locs, labels, matched = O.assign_yolov3(anchors, gb, gl)
+    else:
+        ranges = tables(O)[table.replace('points', 'ranges')]()
+        locs, cents, labels, matched = O.assign_fcos(anchors, ranges, gb, gl)
+    assert np.array_equal(labels.numpy(), z['labels'].astype(np.int64))
+    assert np.array_equal(matched.numpy(), z['matched'].astype(np.int64))
+    assert sha(locs) == str(z['locs_sha256'])          # same torch CPU ops -> same bits
+    if cents is not None:
+        assert sha(cents) == str(z['cents_sha256'])
+    if 'locs' in z.files:
+        assert np.array_equal(locs.numpy(), z['locs'], equal_nan=True)
+    else:
+        assert np.array_equal(locs[z['sub_b'], z['sub_p']].numpy(), z['sub_locs'], equal_nan=True)
+
+
+PREDICT = [('retinanet_small', 'retinanet_small_pboxes'), ('ssd300', 'ssd300_dboxes'),
+           ('retinanet512', 'retinanet512_pboxes'), ('fcos512', 'fcos512_points')]
+
+
+@pytest.mark.parametrize('name,table', PREDICT)
+@pytest.mark.parametrize('fast', [False, True])
+def test_pre_predict_and_predictor_match_reference(oracle, name, table, fast):
+    O = oracle
+    z = load('predict_' + name)
+    anchors = tables(O)[table]()
+    spec, locs, confs, ext = predict_inputs(z, anchors.shape[0])
+    if spec['family'] == 'fcos':
+        pb, ps, pc = O.pre_predict_fcos(locs, confs, ext, anchors, spec['conf_thresh'], spec['top_k'], fast=fast)
+    else:
+        pb, ps, pc = O.pre_predict_softmax(locs, confs, anchors, spec['conf_thresh'], spec['top_k'], fast=fast)
+    counts = z['counts']
+    assert [b.shape[0] for b in pb] == counts.tolist()
+    assert np.array_equal(torch.cat(pc).numpy(), z['class_ids'].astype(np.int64))
+    assert np.array_equal(torch.cat(ps).numpy(), z['scores'])
+    assert np.array_equal(torch.cat(pb).numpy(), z['bboxes'])
+    metas = json.loads(str(z['metas']))
+    result, keeps = O.predictor_run(metas, pb, ps, pc, 0.45, return_keeps=True)
+    assert [k.numel() for k in keeps] == z['keep_counts'].tolist()
+    assert np.array_equal(torch.cat(keeps).numpy(), z['keeps'].astype(np.int64))
+    ids = np.array([[r['image_id'], r['category_id']] for r in result], dtype=np.int64).reshape(-1, 2)
+    vals = np.array([r['bbox'] + [r['score']] for r in result], dtype=np.float64).reshape(-1, 5)
+    assert np.array_equal(ids, z['rows_ids']) and np.array_equal(vals, z['rows_vals'])
+    rid, rv = O.predictor_run_rows(metas, pb, ps, pc, 0.45)
+    assert np.array_equal(rid.numpy(), z['rows_ids']) and np.array_equal(rv.numpy(), z['rows_vals'])
+
+
+def test_nms_c_matches_python_twin(oracle):
+    O = oracle
+    g = torch.Generator().manual_seed(3)
+    for n in (0, 1, 2, 65, 300):
+        c = torch.rand(n, 2, generator=g)
+        wh = 0.05 + 0.3 * torch.rand(n, 2, generator=g)
+        boxes = torch.cat([c - wh / 2, c + wh / 2], 1)
+        scores = (torch.rand(n, generator=g) * 8).round() / 8      # many exact ties
+        if n > 10:
+            boxes[7] = boxes[3]                                     # duplicates
+            boxes[9, 2:] = boxes[9, :2]                             # zero-area
+        for thr in (0.0, 0.3, 0.45, 1.0):
+            assert torch.equal(O.nms(boxes, scores, thr), O.nms_python(boxes, scores, thr))
+
+
+def test_yolov3_pre_predict_is_unpinned():
+    note = manifest()['notes']['yolov3_pre_predict']
+    assert note.startswith('TypeError')   # the reference cannot run it: parity for this path is by formula only
