@@ -1,0 +1,171 @@
+/*
+ * detbox -- C ABI of the MI355X (gfx950) detection box-ops library.
+ *
+ * The reference (rs1004/object_detection) has no FFI layer: its box-ops path is
+ * plain Python on torch + torchvision.ops.  Each entry point below names the
+ * reference code it replaces (paths relative to the reference root) and is what
+ * a binding for that call site would bind.
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory owned by the caller, contiguous, row-major;
+ *     fp32 boxes/scores, int64 labels/class ids/indices, int32 offsets/counts;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all
+ *     work is enqueued asynchronously on it, nothing synchronises the device;
+ *   - functions return DETBOX_OK or a negative DETBOX_ERR_* code and never throw;
+ *     detbox_last_error() returns a thread-local message for the last failure;
+ *   - functions taking `workspace` need `*_workspace_bytes(...)` bytes of
+ *     256-byte-aligned scratch; its contents are undefined afterwards, and two
+ *     calls sharing one workspace must be ordered on one stream;
+ *   - no entry point allocates or frees device memory.
+ */
+#ifndef DETBOX_H
+#define DETBOX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DETBOX_OK 0
+#define DETBOX_ERR_INVALID (-1)     /* bad argument (null pointer, negative size, unknown mode) */
+#define DETBOX_ERR_WORKSPACE (-2)   /* workspace missing, misaligned or too small */
+#define DETBOX_ERR_HIP (-3)         /* a HIP runtime call failed */
+#define DETBOX_ERR_UNSUPPORTED (-4) /* size beyond a documented limit */
+
+/* box formats of torchvision.ops.box_convert */
+#define DETBOX_FMT_XYXY 0
+#define DETBOX_FMT_XYWH 1
+#define DETBOX_FMT_CXCYWH 2
+
+/* anchor-assignment modes */
+#define DETBOX_ASSIGN_CXCYWH 0 /* SSD / RetinaNet: anchors [P,4] cxcywh, GT cxcywh */
+#define DETBOX_ASSIGN_YOLO 1   /* YOLOv3: priors [P,5] = x,y,w,h,grid_length; GT xywh */
+
+/* decode modes */
+#define DETBOX_DECODE_CXCYWH 0 /* anchors [P,4] cxcywh  (SSD / RetinaNet) */
+#define DETBOX_DECODE_YOLO 1   /* priors  [P,5] x,y,w,h,grid  (YOLOv3)    */
+#define DETBOX_DECODE_FCOS 2   /* points  [P,2] pixels  (FCOS)            */
+
+#define DETBOX_MAX_TOP_K 4096     /* largest top_k of detbox_select_decode */
+#define DETBOX_NMS_MAX_SORT 4096  /* largest unsorted segment of detbox_batched_nms_segments */
+
+int detbox_version(void);
+const char *detbox_last_error(void);
+
+/* ---- primitives (torchvision.ops; third-party to the reference) -------------------------- */
+
+/* torchvision.ops.box_convert(boxes[n,4], in_fmt, out_fmt) -> out[n,4].
+ * Reference call sites: src/models/ssd300.py:249-250,374; src/models/retinanet.py:180-181,302;
+ * src/models/yolov3.py:168-169,321; src/models/fcos.py:215; src/datasets/dataset.py:59. */
+int detbox_box_convert(const float *boxes, float *out, int64_t n, int in_fmt, int out_fmt, void *stream);
+
+/* torchvision.ops.box_iou(boxes1[n,4] xyxy, boxes2[m,4] xyxy) -> iou[n,m]  (no epsilon).
+ * Reference call sites: src/models/ssd300.py:251; src/models/retinanet.py:182; src/models/yolov3.py:170. */
+int detbox_box_iou(const float *boxes1, int64_t n, const float *boxes2, int64_t m, float *iou, void *stream);
+
+/* ---- training-time target assignment ("Step 1" of every loss()) -------------------------- */
+
+/* Replaces src/models/ssd300.py:245-266, src/models/retinanet.py:176-198 and
+ * src/models/yolov3.py:161-186 for a whole batch in one call.
+ *   anchors      [P,4] (CXCYWH mode) or [P,5] (YOLO mode)
+ *   gt_boxes     [sum G,4], gt_labels [sum G], gt_offsets [B+1] (image i owns rows
+ *                gt_offsets[i] .. gt_offsets[i+1]-1 of both)
+ *   thr_lo/hi    labels: max_iou < thr_lo -> 0 (background); else max_iou < thr_hi -> -1 (ignore);
+ *                else the label of the arg-max GT.  SSD: lo = hi = 0.5; RetinaNet: 0.4, 0.5;
+ *                YOLOv3: 0.5, 1.0.  The best anchor of every GT has its max_iou replaced by thr_hi
+ *                before labelling (and keeps the label of its OWN arg-max GT, as the reference does).
+ *   target_locs  [B,P,4] encoded offsets of the arg-max GT (ssd300.py:299-318 / yolov3.py:236-257)
+ *   target_labels[B,P], matched [B,P] (arg-max GT index inside the image; lowest index on ties)
+ *   best_anchor  [sum G] or NULL: per GT the anchor of maximal IoU (YOLO: IoU masked by the
+ *                in-grid test), lowest index on ties
+ * An image with no GT gets labels 0, matched -1 and zero offsets (the reference raises). */
+size_t detbox_assign_anchor_workspace_bytes(int64_t total_gt);
+int detbox_assign_anchor(int mode, const float *anchors, int64_t P,
+                         const float *gt_boxes, const int64_t *gt_labels, const int32_t *gt_offsets,
+                         int64_t B, int64_t total_gt, float thr_lo, float thr_hi,
+                         float *target_locs, int64_t *target_labels, int64_t *matched,
+                         int64_t *best_anchor, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Replaces src/models/fcos.py:211-243.  points [P,2], regress_ranges [P,2] (inclusive both ends),
+ * GT cxcywh in pixels.  target_locs [B,P,4] = rays (l,r,t,b) of the matched box, target_cents [B,P],
+ * target_labels [B,P], matched [B,P].  Rows with label 0 hold the rays of GT 0 and a centerness
+ * that may be NaN, exactly like the reference; images with no GT get zeros and matched -1. */
+int detbox_assign_fcos(const float *points, const float *regress_ranges, int64_t P,
+                       const float *gt_boxes, const int64_t *gt_labels, const int32_t *gt_offsets,
+                       int64_t B, int64_t total_gt,
+                       float *target_locs, float *target_cents, int64_t *target_labels, int64_t *matched,
+                       void *stream);
+
+/* ---- inference: threshold + exact top-k + decode ----------------------------------------- */
+
+/* Replaces the per-image, per-class loop of every pre_predict (src/models/ssd300.py:364-382,
+ * src/models/retinanet.py:292-310, src/models/fcos.py:324-341, src/models/yolov3.py:311-329):
+ * for every image b and class c in [class_begin, C) keep the anchors with
+ *     scores[b,p,c] > conf_thresh  and  descending rank of scores[b,:,c] < top_k
+ * (ties at the boundary: lower anchor index wins), decode their boxes to xyxy and emit them
+ * class-major, anchor-index ascending.
+ *   scores        [B,P,C] activated scores; locs [B,P,4]; anchors per decode_mode
+ *   score_hi_hint upper end of the expected score range (1.0 for probabilities).  Speed only.
+ *   out_*         image b owns rows b*stride .. b*stride+out_counts[b]-1, stride = (C-class_begin)*top_k;
+ *                 out_boxes [B*stride,4], out_scores [B*stride], out_class_ids [B*stride]
+ *                 (= c + class_id_offset)
+ *   out_seg_offsets [B, (C-class_begin)+1]: class segment boundaries inside image b's rows
+ *   out_counts    [B]
+ * Limit: 1 <= top_k <= DETBOX_MAX_TOP_K. */
+size_t detbox_select_decode_workspace_bytes(int64_t B, int64_t P, int64_t C, int class_begin, int top_k);
+int detbox_select_decode(int decode_mode, const float *scores, const float *locs, const float *anchors,
+                         int64_t B, int64_t P, int64_t C, int class_begin, int class_id_offset,
+                         float conf_thresh, int top_k, float score_hi_hint,
+                         float *out_boxes, float *out_scores, int64_t *out_class_ids,
+                         int32_t *out_seg_offsets, int32_t *out_counts,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- inference: per-class NMS and result rows -------------------------------------------- */
+
+/* Replaces torchvision.ops.batched_nms as called at src/utilities/predictor.py:55, for a batch whose
+ * boxes are already grouped by class: image b owns rows b*stride.., segment s of image b is rows
+ * seg_offsets[b,s] .. seg_offsets[b,s+1]-1 (relative to the image), S segments per image.
+ * Greedy NMS inside each segment in stable descending score order, suppressing when
+ * (double)iou > iou_threshold; keep[b, 0..keep_counts[b]) are the kept row indices (relative to the
+ * image) of all segments in stable descending score order.
+ *   max_segment   : an upper bound on the segment lengths (e.g. top_k); <= 0 means "unknown" (= stride).
+ *                   It sizes the on-chip buffers; an image holding a longer segment gets keep_counts -1.
+ *   presorted != 0: every segment is already in descending score order (up to 262144 boxes each).
+ *   presorted == 0: segments are sorted here; a segment longer than DETBOX_NMS_MAX_SORT makes
+ *                   keep_counts[b] = -1 for its image. */
+size_t detbox_batched_nms_segments_workspace_bytes(int64_t B, int64_t stride, int64_t S);
+int detbox_batched_nms_segments(const float *boxes, const float *scores, const int32_t *seg_offsets,
+                                int64_t B, int64_t stride, int64_t S, int64_t max_segment,
+                                double iou_threshold, int presorted,
+                                int64_t *keep, int32_t *keep_counts,
+                                void *workspace, size_t workspace_bytes, void *stream);
+
+/* Replaces the per-detection Python loop of src/utilities/predictor.py:56-73: gathers the kept rows
+ * of every image and writes result rows, images in order, detections in keep order:
+ *   rows_ids  [N,2] = image_id, category_id;  rows_vals [N,5] (float64) =
+ *   x1*W, y1*H, (x2-x1)*W, (y2-y1)*H, score   (fp32 differences, float64 products, as in Python)
+ * N = sum keep_counts; row_offsets [B+1] receives the per-image row ranges.  image_sizes [B,2] = H, W. */
+int detbox_pack_detections(const float *boxes, const float *scores, const int64_t *class_ids,
+                           const int64_t *keep, const int32_t *keep_counts,
+                           const int64_t *image_ids, const int32_t *image_sizes,
+                           int64_t B, int64_t stride,
+                           int64_t *rows_ids, double *rows_vals, int32_t *row_offsets, void *stream);
+
+/* ---- per-kernel timing (HIP events on the launch stream) --------------------------------- */
+
+/* While enabled, every kernel launch is bracketed by hipEvents recorded on its stream.
+ * detbox_profile_read synchronises those events and returns the accumulated time and launch
+ * count of the kernel called `name`; reset drops all samples.  Kernel names: "box_convert",
+ * "box_iou", "assign_anchor", "assign_fixup", "assign_fcos", "score_hist", "select_kth",
+ * "select_refine", "select_emit", "select_finalize", "nms_segments", "nms_scan", "nms_merge",
+ * "nms_write", "pack_detections". */
+int detbox_profile_enable(int on);
+int detbox_profile_reset(void);
+int detbox_profile_read(const char *name, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DETBOX_H */

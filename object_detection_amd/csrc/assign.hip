@@ -1,0 +1,322 @@
+// Training-time target assignment for a whole batch.
+//
+// assign_anchor_kernel fuses, per (image, anchor): box conversion, the IoU row
+// against every GT of the image, the row arg-max (matched GT), the label
+// thresholds and the offset encoding, and at the same time reduces the IoU
+// COLUMNS (best anchor per GT) with a wavefront max + ballot and one 64-bit
+// atomicMax per (wave, GT).  The P x G IoU matrix never leaves registers.
+// Replaces src/models/ssd300.py:245-266, src/models/retinanet.py:176-198,
+// src/models/yolov3.py:161-186; assign_fcos_kernel replaces src/models/fcos.py:211-243.
+//
+// Layout: one thread owns one anchor (coalesced float4 loads/stores); the GT
+// boxes of the current image sit in LDS as xyxy + area; a block walks several
+// images so the anchor conversion is paid once.
+//
+// Bit-exactness: every fp32 expression keeps the operation order of the
+// reference (no FMA contraction: the file is built with -ffp-contract=off;
+// division is IEEE-correct).  Ties resolve to the lowest index like torch.max /
+// torch.min on CPU: rows by a strict compare in ascending GT order, columns by
+// packing (iou bits, ~anchor index) into one 64-bit key.
+#include "detbox_internal.h"
+
+using namespace detbox;
+
+namespace {
+
+constexpr int ASSIGN_BLOCK = 256;
+constexpr int GCHUNK = 128;       // GT boxes staged in LDS at a time
+
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
+    const float *__restrict__ anchors, int P,
+    const float4 *__restrict__ gt_boxes, const int64_t *__restrict__ gt_labels,
+    const int32_t *__restrict__ gt_off, int B, int imgs_per_block, float thr_lo, float thr_hi,
+    float4 *__restrict__ locs, int64_t *__restrict__ labels, int64_t *__restrict__ matched,
+    unsigned long long *__restrict__ colbest) {
+    __shared__ float4 s_xyxy[GCHUNK];
+    __shared__ float s_area[GCHUNK];
+    __shared__ float2 s_xy[GCHUNK];                 // YOLO: raw GT top-left
+    __shared__ unsigned long long s_col[GCHUNK];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int p = blockIdx.x * ASSIGN_BLOCK + tid;
+    const bool valid = p < P;
+
+    // anchor in registers: raw (for encoding), xyxy + area (for IoU)
+    float a0 = 0.f, a1 = 0.f, a2 = 1.f, a3 = 1.f, grid = 1.f;
+    if (valid) {
+        if (MODE == DETBOX_ASSIGN_CXCYWH) {
+            float4 a = reinterpret_cast<const float4 *>(anchors)[p];
+            a0 = a.x; a1 = a.y; a2 = a.z; a3 = a.w;
+        } else {
+            const float *a = anchors + (size_t)p * 5;
+            a0 = a[0]; a1 = a[1]; a2 = a[2]; a3 = a[3]; grid = a[4];
+        }
+    }
+    float ax1, ay1, ax2, ay2, gx_hi = 0.f, gy_hi = 0.f;
+    if (MODE == DETBOX_ASSIGN_CXCYWH) {
+        ax1 = a0 - 0.5f * a2; ay1 = a1 - 0.5f * a3; ax2 = a0 + 0.5f * a2; ay2 = a1 + 0.5f * a3;
+    } else {
+        ax1 = a0; ay1 = a1; ax2 = a0 + a2; ay2 = a1 + a3;
+        gx_hi = a0 + grid; gy_hi = a1 + grid;
+    }
+    const float area_a = (ax2 - ax1) * (ay2 - ay1);
+
+    const int b_begin = blockIdx.y * imgs_per_block;
+    const int b_end = min(B, b_begin + imgs_per_block);
+    for (int b = b_begin; b < b_end; ++b) {
+        const int g0 = gt_off[b];
+        const int G = gt_off[b + 1] - g0;
+        const size_t o = (size_t)b * P + p;
+        if (G <= 0) {
+            if (valid) { locs[o] = make_float4(0.f, 0.f, 0.f, 0.f); labels[o] = 0; matched[o] = -1; }
+            continue;
+        }
+        float best = -1.0f;
+        int bidx = 0;
+        for (int c0 = 0; c0 < G; c0 += GCHUNK) {
+            const int gc = min(GCHUNK, G - c0);
+            __syncthreads();
+            if (tid < gc) {
+                float4 g = gt_boxes[g0 + c0 + tid];
+                float4 x;
+                if (MODE == DETBOX_ASSIGN_CXCYWH)
+                    x = make_float4(g.x - 0.5f * g.z, g.y - 0.5f * g.w, g.x + 0.5f * g.z, g.y + 0.5f * g.w);
+                else
+                    x = make_float4(g.x, g.y, g.x + g.z, g.y + g.w);
+                s_xyxy[tid] = x;
+                s_area[tid] = (x.z - x.x) * (x.w - x.y);
+                s_xy[tid] = make_float2(g.x, g.y);
+                s_col[tid] = 0ull;
+            }
+            __syncthreads();
+            for (int j = 0; j < gc; ++j) {
+                const float4 g = s_xyxy[j];
+                const float w = fmaxf(fminf(ax2, g.z) - fmaxf(ax1, g.x), 0.0f);
+                const float h = fmaxf(fminf(ay2, g.w) - fmaxf(ay1, g.y), 0.0f);
+                const float inter = w * h;
+                float iou = 0.0f;
+                // inter == 0 gives exactly +0 (the union is positive), so the division is skipped
+                if (inter > 0.0f) iou = inter / ((area_a + s_area[j]) - inter);
+                if (!valid) iou = 0.0f;
+                if (iou > best) { best = iou; bidx = c0 + j; }
+                float v = iou;
+                if (MODE == DETBOX_ASSIGN_YOLO) {
+                    const float2 q = s_xy[j];
+                    const bool in_grid = (a0 <= q.x) && (q.x < gx_hi) && (a1 <= q.y) && (q.y < gy_hi);
+                    v = in_grid ? iou : 0.0f;
+                }
+                if (__ballot(v > 0.0f) != 0ull) {           // wave-uniform
+                    const float m = wave_max(v);
+                    const unsigned long long eq = __ballot(v == m);
+                    if (lane == __ffsll((long long)eq) - 1) {
+                        const unsigned long long key =
+                            ((unsigned long long)__float_as_uint(m) << 32) | (unsigned long long)(0xffffffffu - (unsigned)p);
+                        atomicMax(&s_col[j], key);
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < gc) {
+                const unsigned long long k = s_col[tid];
+                if (k != 0ull) atomicMax(&colbest[g0 + c0 + tid], k);
+            }
+        }
+        if (valid) {
+            const float4 g = gt_boxes[g0 + bidx];
+            const int64_t lbl = gt_labels[g0 + bidx];
+            float4 d;
+            if (MODE == DETBOX_ASSIGN_CXCYWH) {
+                d.x = (10.0f * (g.x - a0)) / a2;
+                d.y = (10.0f * (g.y - a1)) / a3;
+            } else {
+                d.x = (10.0f * (g.x - a0)) / grid;
+                d.y = (10.0f * (g.y - a1)) / grid;
+            }
+            d.z = 5.0f * logf(g.z / a2);
+            d.w = 5.0f * logf(g.w / a3);
+            locs[o] = d;
+            matched[o] = bidx;
+            labels[o] = (best < thr_lo) ? 0 : ((best < thr_hi) ? -1 : lbl);
+        }
+    }
+}
+
+// The best anchor of every GT is labelled as if its max IoU were thr_hi
+// (`max_ious[best_ids] = thr`, src/models/ssd300.py:258).  It keeps the label
+// of its own arg-max GT: the reference's "assign GT j" loop writes into a
+// temporary (ssd300.py:256-257).
+__global__ __launch_bounds__(256) void assign_fixup_kernel(
+    const unsigned long long *__restrict__ colbest, const int32_t *__restrict__ gt_off, int B, int total_gt, int P,
+    const int64_t *__restrict__ gt_labels, const int64_t *__restrict__ matched, float thr_lo, float thr_hi,
+    int64_t *__restrict__ labels, int64_t *__restrict__ best_anchor) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_gt) return;
+    int lo = 0, hi = B;                      // largest b with gt_off[b] <= t
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (gt_off[mid] <= t) lo = mid; else hi = mid;
+    }
+    const int b = lo;
+    const unsigned long long k = colbest[t];
+    const unsigned pbest = (k == 0ull) ? 0u : (0xffffffffu - (unsigned)(k & 0xffffffffull));
+    if (best_anchor) best_anchor[t] = (int64_t)pbest;
+    const size_t o = (size_t)b * P + pbest;
+    const int64_t m = matched[o];
+    labels[o] = (thr_hi < thr_lo) ? 0 : gt_labels[gt_off[b] + m];
+}
+
+__global__ __launch_bounds__(ASSIGN_BLOCK) void assign_fcos_kernel(
+    const float2 *__restrict__ points, const float2 *__restrict__ ranges, int P,
+    const float4 *__restrict__ gt_boxes, const int64_t *__restrict__ gt_labels,
+    const int32_t *__restrict__ gt_off, int B, int imgs_per_block,
+    float4 *__restrict__ locs, float *__restrict__ cents, int64_t *__restrict__ labels,
+    int64_t *__restrict__ matched) {
+    __shared__ float4 s_xyxy[GCHUNK];
+    __shared__ float s_area[GCHUNK];
+    const float INF = 1e8f;
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x * ASSIGN_BLOCK + tid;
+    const bool valid = p < P;
+    float2 pt = make_float2(0.f, 0.f), rr = make_float2(0.f, 0.f);
+    if (valid) { pt = points[p]; rr = ranges[p]; }
+
+    const int b_begin = blockIdx.y * imgs_per_block;
+    const int b_end = min(B, b_begin + imgs_per_block);
+    for (int b = b_begin; b < b_end; ++b) {
+        const int g0 = gt_off[b];
+        const int G = gt_off[b + 1] - g0;
+        const size_t o = (size_t)b * P + p;
+        if (G <= 0) {
+            if (valid) { locs[o] = make_float4(0.f, 0.f, 0.f, 0.f); cents[o] = 0.f; labels[o] = 0; matched[o] = -1; }
+            continue;
+        }
+        float best = __builtin_inff();
+        int bidx = 0;
+        for (int c0 = 0; c0 < G; c0 += GCHUNK) {
+            const int gc = min(GCHUNK, G - c0);
+            __syncthreads();
+            if (tid < gc) {
+                float4 g = gt_boxes[g0 + c0 + tid];
+                float4 x = make_float4(g.x - 0.5f * g.z, g.y - 0.5f * g.w, g.x + 0.5f * g.z, g.y + 0.5f * g.w);
+                s_xyxy[tid] = x;
+                s_area[tid] = (x.z - x.x) * (x.w - x.y);
+            }
+            __syncthreads();
+            for (int j = 0; j < gc; ++j) {
+                const float4 g = s_xyxy[j];
+                const float l = pt.x - g.x, r = g.z - pt.x, t = pt.y - g.y, bt = g.w - pt.y;
+                const float mn = fminf(fminf(l, r), fminf(t, bt));
+                const float mx = fmaxf(fmaxf(l, r), fmaxf(t, bt));
+                const bool ok = (mn > 0.0f) && (rr.x <= mx) && (mx <= rr.y);
+                const float area = ok ? s_area[j] : INF;
+                if (area < best) { best = area; bidx = c0 + j; }
+            }
+        }
+        if (valid) {
+            const float4 g = gt_boxes[g0 + bidx];
+            const float x1 = g.x - 0.5f * g.z, y1 = g.y - 0.5f * g.w, x2 = g.x + 0.5f * g.z, y2 = g.y + 0.5f * g.w;
+            const float l = pt.x - x1, r = x2 - pt.x, t = pt.y - y1, bt = y2 - pt.y;
+            locs[o] = make_float4(l, r, t, bt);
+            // a / b * c / d evaluated left to right (src/models/fcos.py:235-237)
+            cents[o] = sqrtf(((fminf(l, r) / fmaxf(l, r)) * fminf(t, bt)) / fmaxf(t, bt));
+            matched[o] = bidx;
+            labels[o] = (best == INF) ? 0 : gt_labels[g0 + bidx];
+        }
+    }
+}
+
+int pick_imgs_per_block(int64_t tiles, int64_t B) {
+    // enough blocks to fill 256 CUs several times over, few enough that the anchor setup amortises
+    int64_t ipb = (tiles * B) / 4096;
+    if (ipb < 1) ipb = 1;
+    if (ipb > B) ipb = B;
+    while ((B + ipb - 1) / ipb > 65535) ++ipb;
+    return (int)ipb;
+}
+
+}  // namespace
+
+extern "C" size_t detbox_assign_anchor_workspace_bytes(int64_t total_gt) {
+    if (total_gt < 0) total_gt = 0;
+    return align_up((size_t)total_gt * sizeof(unsigned long long) + 256, 256);
+}
+
+extern "C" int detbox_assign_anchor(int mode, const float *anchors, int64_t P,
+                                    const float *gt_boxes, const int64_t *gt_labels, const int32_t *gt_offsets,
+                                    int64_t B, int64_t total_gt, float thr_lo, float thr_hi,
+                                    float *target_locs, int64_t *target_labels, int64_t *matched,
+                                    int64_t *best_anchor, void *workspace, size_t workspace_bytes, void *stream) {
+    DETBOX_CHECK_ARG(mode == DETBOX_ASSIGN_CXCYWH || mode == DETBOX_ASSIGN_YOLO, "unknown mode");
+    DETBOX_CHECK_ARG(P >= 0 && B >= 0 && total_gt >= 0, "negative size");
+    DETBOX_CHECK_ARG(P < (1ll << 31) && total_gt < (1ll << 31), "P and total_gt must fit 31 bits");
+    if (P == 0 || B == 0) return DETBOX_OK;
+    DETBOX_CHECK_ARG(anchors && gt_offsets && target_locs && target_labels && matched, "null pointer");
+    DETBOX_CHECK_ARG(total_gt == 0 || (gt_boxes && gt_labels), "null GT pointer");
+    DETBOX_CHECK_ARG((uintptr_t)target_locs % 16 == 0 && (uintptr_t)gt_boxes % 16 == 0, "float4 arrays must be 16-byte aligned");
+    DETBOX_CHECK_ARG(mode != DETBOX_ASSIGN_CXCYWH || (uintptr_t)anchors % 16 == 0, "anchors must be 16-byte aligned");
+    if (workspace_bytes < detbox_assign_anchor_workspace_bytes(total_gt) || !workspace || (uintptr_t)workspace % 256) {
+        set_error("detbox_assign_anchor: workspace missing, misaligned or smaller than %zu bytes",
+                  detbox_assign_anchor_workspace_bytes(total_gt));
+        return DETBOX_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned long long *colbest = static_cast<unsigned long long *>(workspace);
+    if (total_gt > 0) DETBOX_HIP(hipMemsetAsync(colbest, 0, (size_t)total_gt * sizeof(unsigned long long), s));
+    const int64_t tiles = (P + ASSIGN_BLOCK - 1) / ASSIGN_BLOCK;
+    const int ipb = pick_imgs_per_block(tiles, B);
+    dim3 grid((unsigned)tiles, (unsigned)((B + ipb - 1) / ipb));
+    {
+        ProfScope ps("assign_anchor", s);
+        if (mode == DETBOX_ASSIGN_CXCYWH)
+            assign_anchor_kernel<DETBOX_ASSIGN_CXCYWH><<<grid, dim3(ASSIGN_BLOCK), 0, s>>>(
+                anchors, (int)P, reinterpret_cast<const float4 *>(gt_boxes), gt_labels, gt_offsets, (int)B, ipb,
+                thr_lo, thr_hi, reinterpret_cast<float4 *>(target_locs), target_labels, matched, colbest);
+        else
+            assign_anchor_kernel<DETBOX_ASSIGN_YOLO><<<grid, dim3(ASSIGN_BLOCK), 0, s>>>(
+                anchors, (int)P, reinterpret_cast<const float4 *>(gt_boxes), gt_labels, gt_offsets, (int)B, ipb,
+                thr_lo, thr_hi, reinterpret_cast<float4 *>(target_locs), target_labels, matched, colbest);
+        DETBOX_LAUNCH_CHECK();
+    }
+    if (total_gt > 0) {
+        ProfScope ps("assign_fixup", s);
+        assign_fixup_kernel<<<dim3((unsigned)((total_gt + 255) / 256)), dim3(256), 0, s>>>(
+            colbest, gt_offsets, (int)B, (int)total_gt, (int)P, gt_labels, matched, thr_lo, thr_hi, target_labels,
+            best_anchor);
+        DETBOX_LAUNCH_CHECK();
+    }
+    return DETBOX_OK;
+}
+
+extern "C" int detbox_assign_fcos(const float *points, const float *regress_ranges, int64_t P,
+                                  const float *gt_boxes, const int64_t *gt_labels, const int32_t *gt_offsets,
+                                  int64_t B, int64_t total_gt,
+                                  float *target_locs, float *target_cents, int64_t *target_labels, int64_t *matched,
+                                  void *stream) {
+    DETBOX_CHECK_ARG(P >= 0 && B >= 0 && total_gt >= 0, "negative size");
+    DETBOX_CHECK_ARG(P < (1ll << 31) && total_gt < (1ll << 31), "P and total_gt must fit 31 bits");
+    if (P == 0 || B == 0) return DETBOX_OK;
+    DETBOX_CHECK_ARG(points && regress_ranges && gt_offsets && target_locs && target_cents && target_labels && matched,
+                     "null pointer");
+    DETBOX_CHECK_ARG(total_gt == 0 || (gt_boxes && gt_labels), "null GT pointer");
+    DETBOX_CHECK_ARG((uintptr_t)target_locs % 16 == 0 && (uintptr_t)gt_boxes % 16 == 0 &&
+                     (uintptr_t)points % 8 == 0 && (uintptr_t)regress_ranges % 8 == 0, "misaligned array");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t tiles = (P + ASSIGN_BLOCK - 1) / ASSIGN_BLOCK;
+    const int ipb = pick_imgs_per_block(tiles, B);
+    dim3 grid((unsigned)tiles, (unsigned)((B + ipb - 1) / ipb));
+    ProfScope ps("assign_fcos", s);
+    assign_fcos_kernel<<<grid, dim3(ASSIGN_BLOCK), 0, s>>>(
+        reinterpret_cast<const float2 *>(points), reinterpret_cast<const float2 *>(regress_ranges), (int)P,
+        reinterpret_cast<const float4 *>(gt_boxes), gt_labels, gt_offsets, (int)B, ipb,
+        reinterpret_cast<float4 *>(target_locs), target_cents, target_labels, matched);
+    DETBOX_LAUNCH_CHECK();
+    return DETBOX_OK;
+}

@@ -1,0 +1,60 @@
+// Internal helpers shared by the detbox translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/detbox.h"
+
+namespace detbox {
+
+// thread-local error text returned by detbox_last_error()
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);
+
+// per-kernel hipEvent timing (detbox_profile_*); begin/end are no-ops while disabled
+void prof_begin(const char *name, hipStream_t s);
+void prof_end(const char *name, hipStream_t s);
+
+struct ProfScope {
+    const char *name; hipStream_t s;
+    ProfScope(const char *n, hipStream_t st) : name(n), s(st) { prof_begin(name, s); }
+    ~ProfScope() { prof_end(name, s); }
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Carves 256-byte aligned regions out of a caller-provided workspace.
+struct Carver {
+    char *base; size_t off;
+    explicit Carver(void *p) : base(static_cast<char *>(p)), off(0) {}
+    template <typename T> T *take(size_t count) {
+        T *r = reinterpret_cast<T *>(base + off);
+        off = align_up(off + count * sizeof(T), 256);
+        return r;
+    }
+};
+
+#define DETBOX_CHECK_ARG(cond, msg)                                   \
+    do { if (!(cond)) { detbox::set_error("%s: %s", __func__, msg);   \
+                        return DETBOX_ERR_INVALID; } } while (0)
+
+#define DETBOX_HIP(call)                                              \
+    do { hipError_t e_ = (call);                                      \
+         if (e_ != hipSuccess) return detbox::hip_fail(e_, #call); } while (0)
+
+#define DETBOX_LAUNCH_CHECK()                                         \
+    do { hipError_t e_ = hipGetLastError();                           \
+         if (e_ != hipSuccess) return detbox::hip_fail(e_, "kernel launch"); } while (0)
+
+// ---- device helpers ---------------------------------------------------------------------
+
+// Monotone map of fp32 onto uint32: a < b  <=>  okey(a) < okey(b) (for non-NaN, with -0 == +0).
+__device__ __host__ inline uint32_t okey_from_bits(uint32_t u) {
+    if (u == 0x80000000u) u = 0u;                       // -0 -> +0
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __host__ inline uint32_t bits_from_okey(uint32_t k) {
+    return (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+}
+
+}  // namespace detbox

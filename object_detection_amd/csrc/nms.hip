@@ -1,0 +1,446 @@
+// Per-class (segmented) greedy NMS for a whole batch, plus the result-row packing.
+// Replaces torchvision.ops.batched_nms as called at src/utilities/predictor.py:55
+// and the per-detection Python loop of src/utilities/predictor.py:56-73.
+//
+// nms_segments   one workgroup per (image, class segment): stable descending sort
+//                of the segment (bitonic on 64-bit keys in LDS), boxes gathered into
+//                LDS in that order, then a blocked greedy sweep: for every 64-box
+//                chunk the 64x64 suppression words are built by all four waves, one
+//                wave resolves the chunk serially with readlane on the LDS-resident
+//                words, and the boxes it kept knock out later boxes in parallel
+//                (suppression bitmap in LDS).  Only kept boxes ever act as
+//                suppressors, exactly like the sequential CPU algorithm.
+// nms_scan       per image: offsets of the kept runs.
+// nms_merge      log2(S) stable merge levels (rank by binary search in the sibling
+//                run) turn the per-class kept runs into one list per image in
+//                descending score order -- the order torchvision returns.
+//
+// IoU arithmetic follows torchvision's CPU kernel: areas (x2-x1)*(y2-y1),
+// inter / (area_i + area_j - inter) in fp32, suppressed iff (double)iou > threshold;
+// the host passes the largest fp32 not above the double threshold, which makes the
+// fp32 comparison equivalent.
+#include "detbox_internal.h"
+
+#include <cmath>
+
+using namespace detbox;
+
+namespace {
+
+constexpr int NMS_BLOCK = 256;
+constexpr int NMS_LDS_BOXES = 4096;       // segments up to this length keep their boxes in LDS
+constexpr int NMS_MAX_SEGMENT = 262144;   // bitmap limit for presorted segments
+
+struct NmsParams {
+    int S, max_seg, n2, in_lds, presorted, thr_neg;
+    long long stride;
+    float thr;
+};
+
+struct NmsLds { size_t keys, removed, maskq, keepw, wprefix, box, total; };
+
+// Byte offsets of the dynamic-LDS regions, every one 16-byte aligned.
+__host__ __device__ inline NmsLds nms_lds(int max_seg, int n2, int presorted, int in_lds) {
+    const size_t words_cap = (size_t)((max_seg + 63) >> 6);
+    NmsLds l;
+    size_t off = 0;
+    l.keys = off;    off += presorted ? 0 : (size_t)n2 * 8;            // sort keys, later the order
+    l.removed = off; off += ((words_cap * 8 + 15) & ~(size_t)15);       // suppression bitmap
+    l.maskq = off;   off += 256 * 8;                                    // 4 x 64 partial chunk words
+    l.keepw = off;   off += 16;                                         // kept word of the chunk
+    l.wprefix = off; off += ((words_cap * 4 + 15) & ~(size_t)15);       // kept-count prefix per word
+    l.box = off;     off += in_lds ? (size_t)max_seg * 16 : 0;          // boxes in sorted order
+    l.total = off;
+    return l;
+}
+
+__device__ inline bool iou_gt(const float4 a, const float area_a, const float4 b, const float thr, const int thr_neg) {
+    const float w = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.0f);
+    const float h = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y), 0.0f);
+    const float inter = w * h;
+    if (!(inter > 0.0f) && !thr_neg) return false;      // iou is 0 (or NaN): never above a threshold >= 0
+    const float area_b = (b.z - b.x) * (b.w - b.y);
+    const float ovr = inter / ((area_a + area_b) - inter);
+    return ovr > thr;
+}
+
+__device__ inline void bitonic_desc_u64(unsigned long long *s, int n) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const int x = i ^ j;
+                if (x > i) {
+                    const unsigned long long a = s[i], c = s[x];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < c) : (a > c)) { s[i] = c; s[x] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ inline unsigned long long uniform64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ inline unsigned long long readlane64(unsigned long long v, int l) {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(NMS_BLOCK) void nms_segments_kernel(
+    const float4 *__restrict__ boxes, const float *__restrict__ scores, const int32_t *__restrict__ seg_off,
+    NmsParams np, float2 *__restrict__ kept, int32_t *__restrict__ kcount, int32_t *__restrict__ err) {
+    extern __shared__ unsigned long long s_dyn[];
+    const int s = blockIdx.x, b = blockIdx.y;
+    const int32_t *so = seg_off + (size_t)b * (np.S + 1);
+    const int seg0 = so[s];
+    const int n = so[s + 1] - seg0;
+    if (threadIdx.x == 0) kcount[(size_t)b * np.S + s] = 0;
+    if (n <= 0) return;
+    if (n > np.max_seg || (!np.presorted && n > DETBOX_NMS_MAX_SORT)) {
+        if (threadIdx.x == 0) err[b] = 1;
+        return;
+    }
+    // LDS carve-up (sizes fixed by the host from max_seg)
+    const NmsLds ld = nms_lds(np.max_seg, np.n2, np.presorted, np.in_lds);
+    char *lds_base = reinterpret_cast<char *>(s_dyn);
+    unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(lds_base + ld.keys);
+    unsigned long long *s_removed = reinterpret_cast<unsigned long long *>(lds_base + ld.removed);
+    unsigned long long *s_maskq = reinterpret_cast<unsigned long long *>(lds_base + ld.maskq);
+    unsigned long long *s_keepw = reinterpret_cast<unsigned long long *>(lds_base + ld.keepw);
+    uint32_t *s_wprefix = reinterpret_cast<uint32_t *>(lds_base + ld.wprefix);
+    float4 *s_box = reinterpret_cast<float4 *>(lds_base + ld.box);
+
+    const size_t row0 = (size_t)b * np.stride + seg0;
+    const int tid = threadIdx.x;
+    const int words = (n + 63) >> 6;
+
+    if (!np.presorted) {
+        int n2 = 2;
+        while (n2 < n) n2 <<= 1;
+        for (int i = tid; i < n2; i += NMS_BLOCK) {
+            unsigned long long k = 0ull;
+            if (i < n) {
+                // every real key is above the zero padding: its low word is 0xffffffff - i > 0
+                k = ((unsigned long long)okey_from_bits(__float_as_uint(scores[row0 + i])) << 32) |
+                    (unsigned long long)(0xffffffffu - (uint32_t)i);
+            }
+            s_keys[i] = k;
+        }
+        __syncthreads();
+        bitonic_desc_u64(s_keys, n2);
+    }
+    auto order_of = [&](int i) -> int {
+        return np.presorted ? i : (int)(0xffffffffu - (uint32_t)(s_keys[i] & 0xffffffffull));
+    };
+    if (np.in_lds)
+        for (int i = tid; i < n; i += NMS_BLOCK) s_box[i] = boxes[row0 + order_of(i)];
+    for (int i = tid; i < words; i += NMS_BLOCK) s_removed[i] = 0ull;
+    __syncthreads();
+    auto box_of = [&](int i) -> float4 { return np.in_lds ? s_box[i] : boxes[row0 + order_of(i)]; };
+
+    const int lane = tid & 63, q = tid >> 6;
+    for (int ch = 0; ch < words; ++ch) {
+        const int c0 = ch << 6;
+        const int cn = min(64, n - c0);
+        const unsigned long long valid = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
+        const unsigned long long alive0 = ~s_removed[ch] & valid;
+        // 64x64 suppression words of this chunk: thread (lane, q) covers columns q*16..q*16+15
+        {
+            unsigned long long part = 0ull;
+            if (lane < cn && ((alive0 >> lane) & 1ull)) {
+                const float4 bi = box_of(c0 + lane);
+                const float ai = (bi.z - bi.x) * (bi.w - bi.y);
+                const int j0 = max(q * 16, lane + 1), j1 = min(q * 16 + 16, cn);
+                for (int j = j0; j < j1; ++j)
+                    if (iou_gt(bi, ai, box_of(c0 + j), np.thr, np.thr_neg)) part |= 1ull << j;
+            }
+            s_maskq[q * 64 + lane] = part;
+        }
+        __syncthreads();
+        if (q == 0) {
+            const unsigned long long m = s_maskq[lane] | s_maskq[64 + lane] | s_maskq[128 + lane] | s_maskq[192 + lane];
+            unsigned long long alive = uniform64(alive0);
+            unsigned long long keep = 0ull;
+            while (alive) {
+                const int i = __ffsll((long long)alive) - 1;
+                keep |= 1ull << i;
+                alive &= ~readlane64(m, i);
+                alive &= ~(1ull << i);
+            }
+            if (lane == 0) { s_keepw[0] = keep; s_removed[ch] = valid & ~keep; }
+        }
+        __syncthreads();
+        const unsigned long long keep = s_keepw[0];
+        if (keep != 0ull) {
+            for (int j = c0 + 64 + tid; j < n; j += NMS_BLOCK) {
+                if ((s_removed[j >> 6] >> (j & 63)) & 1ull) continue;
+                const float4 bj = box_of(j);
+                const float aj = (bj.z - bj.x) * (bj.w - bj.y);
+                unsigned long long kk = keep;
+                while (kk) {
+                    const int i = __ffsll((long long)kk) - 1;
+                    kk &= kk - 1ull;
+                    const float4 bi = box_of(c0 + i);
+                    // same operand roles as the sequential algorithm: i is the kept box, j the candidate
+                    const float ai = (bi.z - bi.x) * (bi.w - bi.y);
+                    const float w = fmaxf(fminf(bi.z, bj.z) - fmaxf(bi.x, bj.x), 0.0f);
+                    const float h = fmaxf(fminf(bi.w, bj.w) - fmaxf(bi.y, bj.y), 0.0f);
+                    const float inter = w * h;
+                    if (!(inter > 0.0f) && !np.thr_neg) continue;
+                    const float ovr = inter / ((ai + aj) - inter);
+                    if (ovr > np.thr) { atomicOr(&s_removed[j >> 6], 1ull << (j & 63)); break; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // kept = not removed; compact in sorted order
+    if (q == 0) {
+        uint32_t running = 0;
+        for (int base = 0; base < words; base += 64) {
+            const int w = base + lane;
+            uint32_t pc = 0;
+            if (w < words) {
+                const int cn = min(64, n - (w << 6));
+                const unsigned long long valid = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
+                pc = (uint32_t)__popcll(~s_removed[w] & valid);
+            }
+            uint32_t inc = pc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(inc, o);
+                if (lane >= o) inc += up;
+            }
+            if (w < words) s_wprefix[w] = running + inc - pc;
+            running += __shfl(inc, 63);
+        }
+        if (lane == 0) kcount[(size_t)b * np.S + s] = (int32_t)running;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += NMS_BLOCK) {
+        const unsigned long long rem = s_removed[i >> 6];
+        if ((rem >> (i & 63)) & 1ull) continue;
+        const uint32_t rank = s_wprefix[i >> 6] + (uint32_t)__popcll(~rem & ((1ull << (i & 63)) - 1ull));
+        const int pos = seg0 + order_of(i);
+        kept[row0 + rank] = make_float2(scores[(size_t)b * np.stride + pos], __int_as_float(pos));
+    }
+}
+
+__global__ __launch_bounds__(256) void nms_scan_kernel(const int32_t *__restrict__ kcount, int S,
+                                                       int32_t *__restrict__ koff, const int32_t *__restrict__ err,
+                                                       int32_t *__restrict__ keep_counts) {
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    int acc = 0;
+    const int32_t *kc = kcount + (size_t)b * S;
+    int32_t *ko = koff + (size_t)b * (S + 1);
+    for (int s = 0; s < S; ++s) { ko[s] = acc; acc += kc[s]; }
+    ko[S] = acc;
+    keep_counts[b] = err[b] ? -1 : acc;
+}
+
+// One stable merge level.  Runs at this level are groups of (1 << level) class segments; element t
+// of image b finds its rank inside the sibling run by binary search on the (descending) scores.
+__global__ __launch_bounds__(256) void nms_merge_kernel(
+    const float2 *__restrict__ src, float2 *__restrict__ dst, int64_t *__restrict__ keep_out,
+    const int32_t *__restrict__ koff, const int32_t *__restrict__ seg_off, int S, long long stride, int level,
+    int gapped, int last) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t *ko = koff + (size_t)b * (S + 1);
+    const int total = ko[S];
+    if (t >= total) return;
+    int lo = 0, hi = S;                          // largest s with ko[s] <= t
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (ko[mid] <= t) lo = mid; else hi = mid;
+    }
+    const int s = lo;
+    const int32_t *so = seg_off + (size_t)b * (S + 1);
+    const size_t base = (size_t)b * stride;
+    const int run = s >> level, sib = run ^ 1;
+    const int own_start = ko[min(S, run << level)];
+    const int sib_lo = ko[min(S, sib << level)], sib_hi = ko[min(S, (sib + 1) << level)];
+    // gapped (level 0 only): run == segment, element r of segment x sits at seg_off[x] + r
+    const int sib_shift = gapped ? (so[min(S, sib)] - sib_lo) : 0;
+    const float2 me = src[base + (gapped ? so[s] + (t - ko[s]) : t)];
+    const bool sib_is_right = (run & 1) == 0;
+    int a = sib_lo, c = sib_hi;                  // first sibling index that does NOT precede me
+    while (a < c) {
+        const int mid = (a + c) >> 1;
+        const float sv = src[base + mid + sib_shift].x;
+        const bool precedes = sib_is_right ? (sv > me.x) : (sv >= me.x);
+        if (precedes) a = mid + 1; else c = mid;
+    }
+    const int out = min(own_start, sib_lo) + (t - own_start) + (a - sib_lo);
+    if (last) keep_out[base + out] = (int64_t)__float_as_int(me.y);
+    else dst[base + out] = me;
+}
+
+__global__ __launch_bounds__(256) void pack_detections_kernel(
+    const float4 *__restrict__ boxes, const float *__restrict__ scores, const int64_t *__restrict__ cls,
+    const int64_t *__restrict__ keep, const int32_t *__restrict__ keep_counts,
+    const int64_t *__restrict__ image_ids, const int32_t *__restrict__ image_sizes, int B, long long stride,
+    int64_t *__restrict__ rows_ids, double *__restrict__ rows_vals, int32_t *__restrict__ row_offsets) {
+    __shared__ int s_red[256];
+    const int b = blockIdx.y;
+    int acc = 0;
+    for (int i = threadIdx.x; i < b; i += blockDim.x) acc += max(keep_counts[i], 0);
+    s_red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const int row0 = s_red[0];
+    const int n = max(keep_counts[b], 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        row_offsets[b] = row0;
+        if (b == B - 1) row_offsets[B] = row0 + n;
+    }
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const size_t base = (size_t)b * stride;
+    const int64_t k = keep[base + t];
+    const float4 bx = boxes[base + k];
+    const double W = (double)image_sizes[2 * b + 1], H = (double)image_sizes[2 * b];
+    const size_t r = (size_t)row0 + t;
+    rows_ids[2 * r] = image_ids[b];
+    rows_ids[2 * r + 1] = cls[base + k];
+    rows_vals[5 * r + 0] = (double)bx.x * W;
+    rows_vals[5 * r + 1] = (double)bx.y * H;
+    rows_vals[5 * r + 2] = (double)(bx.z - bx.x) * W;
+    rows_vals[5 * r + 3] = (double)(bx.w - bx.y) * H;
+    rows_vals[5 * r + 4] = (double)scores[base + k];
+}
+
+struct NmsLayout { size_t kept_a, kept_b, kcount, koff, err, total, zero_off, zero_bytes; };
+
+NmsLayout nms_layout(int64_t B, int64_t stride, int64_t S) {
+    NmsLayout L;
+    size_t off = 0;
+    L.kept_a = off; off = align_up(off + (size_t)B * stride * sizeof(float2), 256);
+    L.kept_b = off; off = align_up(off + (size_t)B * stride * sizeof(float2), 256);
+    L.kcount = off; off = align_up(off + (size_t)B * S * sizeof(int32_t), 256);
+    L.koff = off; off = align_up(off + (size_t)B * (S + 1) * sizeof(int32_t), 256);
+    L.zero_off = off;
+    L.err = off; off = align_up(off + (size_t)B * sizeof(int32_t), 256);
+    L.zero_bytes = off - L.zero_off;
+    L.total = off;
+    return L;
+}
+
+}  // namespace
+
+extern "C" size_t detbox_batched_nms_segments_workspace_bytes(int64_t B, int64_t stride, int64_t S) {
+    if (B <= 0 || stride <= 0 || S <= 0) return 256;
+    return nms_layout(B, stride, S).total;
+}
+
+extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scores, const int32_t *seg_offsets,
+                                           int64_t B, int64_t stride, int64_t S, int64_t max_segment,
+                                           double iou_threshold, int presorted,
+                                           int64_t *keep, int32_t *keep_counts,
+                                           void *workspace, size_t workspace_bytes, void *stream) {
+    DETBOX_CHECK_ARG(B >= 0 && stride >= 0 && S >= 0, "negative size");
+    DETBOX_CHECK_ARG(!(iou_threshold != iou_threshold), "iou_threshold is NaN");
+    DETBOX_CHECK_ARG(B <= 65535 && S <= (1 << 30) && stride < (1ll << 31), "size too large");
+    if (B == 0) return DETBOX_OK;
+    DETBOX_CHECK_ARG(keep_counts, "null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (stride == 0 || S == 0) {
+        DETBOX_HIP(hipMemsetAsync(keep_counts, 0, (size_t)B * sizeof(int32_t), st));
+        return DETBOX_OK;
+    }
+    DETBOX_CHECK_ARG(boxes && scores && seg_offsets && keep, "null pointer");
+    DETBOX_CHECK_ARG((uintptr_t)boxes % 16 == 0, "boxes must be 16-byte aligned");
+    if (max_segment <= 0 || max_segment > stride) max_segment = stride;
+    if (!presorted && max_segment > DETBOX_NMS_MAX_SORT) max_segment = DETBOX_NMS_MAX_SORT;
+    if (max_segment > NMS_MAX_SEGMENT) {
+        set_error("detbox_batched_nms_segments: segments longer than %d are not supported", NMS_MAX_SEGMENT);
+        return DETBOX_ERR_UNSUPPORTED;
+    }
+    const NmsLayout L = nms_layout(B, stride, S);
+    if (!workspace || (uintptr_t)workspace % 256 || workspace_bytes < L.total) {
+        set_error("detbox_batched_nms_segments: workspace missing, misaligned or smaller than %zu bytes", L.total);
+        return DETBOX_ERR_WORKSPACE;
+    }
+    char *ws = static_cast<char *>(workspace);
+    float2 *kept_a = reinterpret_cast<float2 *>(ws + L.kept_a);
+    float2 *kept_b = reinterpret_cast<float2 *>(ws + L.kept_b);
+    int32_t *kcount = reinterpret_cast<int32_t *>(ws + L.kcount);
+    int32_t *koff = reinterpret_cast<int32_t *>(ws + L.koff);
+    int32_t *err = reinterpret_cast<int32_t *>(ws + L.err);
+    DETBOX_HIP(hipMemsetAsync(ws + L.zero_off, 0, L.zero_bytes, st));
+
+    NmsParams np;
+    np.S = (int)S; np.max_seg = (int)max_segment; np.presorted = presorted ? 1 : 0;
+    np.stride = stride;
+    np.in_lds = max_segment <= NMS_LDS_BOXES ? 1 : 0;
+    int n2 = 2;
+    while (n2 < max_segment) n2 <<= 1;
+    np.n2 = n2;
+    // largest fp32 <= threshold: (double)x > threshold  <=>  x > thr for every fp32 x
+    float t32 = (float)iou_threshold;
+    if ((double)t32 > iou_threshold) t32 = std::nextafterf(t32, -INFINITY);
+    np.thr = t32;
+    np.thr_neg = iou_threshold < 0.0 ? 1 : 0;
+    const size_t lds = nms_lds(np.max_seg, np.n2, np.presorted, np.in_lds).total;
+    {
+        ProfScope ps("nms_segments", st);
+        if (lds > 64 * 1024)
+            DETBOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_segments_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        nms_segments_kernel<<<dim3((unsigned)S, (unsigned)B), dim3(NMS_BLOCK), lds, st>>>(
+            reinterpret_cast<const float4 *>(boxes), scores, seg_offsets, np, kept_a, kcount, err);
+        DETBOX_LAUNCH_CHECK();
+    }
+    {
+        ProfScope ps("nms_scan", st);
+        nms_scan_kernel<<<dim3((unsigned)B), dim3(64), 0, st>>>(kcount, (int)S, koff, err, keep_counts);
+        DETBOX_LAUNCH_CHECK();
+    }
+    int levels = 0;
+    while ((1ll << levels) < S) ++levels;
+    if (levels < 1) levels = 1;
+    dim3 grid((unsigned)((stride + 255) / 256), (unsigned)B);
+    float2 *src = kept_a, *dst = kept_b;
+    for (int lv = 0; lv < levels; ++lv) {
+        ProfScope ps("nms_merge", st);
+        nms_merge_kernel<<<grid, dim3(256), 0, st>>>(src, dst, keep, koff, seg_offsets, (int)S, stride, lv,
+                                                     lv == 0 ? 1 : 0, lv == levels - 1 ? 1 : 0);
+        DETBOX_LAUNCH_CHECK();
+        float2 *tmp = src; src = dst; dst = tmp;
+    }
+    return DETBOX_OK;
+}
+
+extern "C" int detbox_pack_detections(const float *boxes, const float *scores, const int64_t *class_ids,
+                                      const int64_t *keep, const int32_t *keep_counts,
+                                      const int64_t *image_ids, const int32_t *image_sizes,
+                                      int64_t B, int64_t stride,
+                                      int64_t *rows_ids, double *rows_vals, int32_t *row_offsets, void *stream) {
+    DETBOX_CHECK_ARG(B >= 0 && stride >= 0, "negative size");
+    DETBOX_CHECK_ARG(B <= 65535 && stride < (1ll << 31), "size too large");
+    DETBOX_CHECK_ARG(row_offsets, "null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (B == 0 || stride == 0) {
+        DETBOX_HIP(hipMemsetAsync(row_offsets, 0, (size_t)(B + 1) * sizeof(int32_t), st));
+        return DETBOX_OK;
+    }
+    DETBOX_CHECK_ARG(boxes && scores && class_ids && keep && keep_counts && image_ids && image_sizes && rows_ids && rows_vals,
+                     "null pointer");
+    DETBOX_CHECK_ARG((uintptr_t)boxes % 16 == 0, "boxes must be 16-byte aligned");
+    ProfScope ps("pack_detections", st);
+    pack_detections_kernel<<<dim3((unsigned)((stride + 255) / 256), (unsigned)B), dim3(256), 0, st>>>(
+        reinterpret_cast<const float4 *>(boxes), scores, class_ids, keep, keep_counts, image_ids, image_sizes, (int)B,
+        stride, rows_ids, rows_vals, row_offsets);
+    DETBOX_LAUNCH_CHECK();
+    return DETBOX_OK;
+}

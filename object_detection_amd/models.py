@@ -1,0 +1,256 @@
+"""Box-ops halves of the reference's detection models, on the HIP operators.
+
+Each class mirrors the interface of its namesake in the reference
+(`DetectionNet`, src/models/base.py:45-51): `loss(outputs, gt_bboxes, gt_labels, ...)`
+and `pre_predict(outputs, conf_thresh=0.01, top_k=200)` with the same argument
+meaning and return types, so `train.py:149,155-156` and `test.py:98-99` work
+unchanged when a model's two methods are bound to these.  The conv network is not
+part of this package: a class here holds only the anchor/point table.
+
+Inside `loss`, Step 1 (target assignment) is one batched HIP call; Steps 2-5 are
+the reference's differentiable loss arithmetic in plain PyTorch.  `pre_predict`
+keeps the activation in PyTorch-ROCm and hands the activated scores to the HIP
+threshold/top-k/decode path.  `detect` chains pre_predict -> NMS -> result rows
+without leaving the device.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import anchors as A
+from . import ops
+
+
+def focal_loss(input, target, alpha=0.25, gamma=2, reduction='none'):
+    """src/models/losses.py:5-9."""
+    pt = F.softmax(input, dim=-1)
+    log_pt = F.log_softmax(input, dim=-1)
+    return F.nll_loss(alpha * (1 - pt).pow(gamma) * log_pt, target, reduction=reduction)
+
+
+def iou_loss_with_distance(input, target, reduction='none'):
+    """src/models/losses.py:12-29 (rays ordered l, r, t, b)."""
+    def area(t):
+        return (t[:, 1] + t[:, 0]) * (t[:, 3] + t[:, 2])
+    inter = area(torch.minimum(input, target))
+    union = area(input) + area(target) - inter
+    loss = -(inter / union.clamp(min=1e-8)).log()
+    return loss.sum() if reduction == 'sum' else (loss.mean() if reduction == 'mean' else loss)
+
+
+class _BoxOps:
+    """Shared plumbing: device-resident anchor table, candidate selection, fused detection."""
+    decode_mode = ops.DECODE_CXCYWH
+    class_begin = 1          # column 0 is background for the softmax heads
+    class_id_offset = 0
+    return_cpu = True        # pre_predict returns CPU tensors like the reference (ssd300.py:357-358)
+
+    def __init__(self):
+        self._dev_tables = {}
+
+    def _table(self, t: torch.Tensor, device) -> torch.Tensor:
+        key = (id(t), str(device))
+        if key not in self._dev_tables:
+            self._dev_tables[key] = t.to(device=device, dtype=torch.float32).contiguous()
+        return self._dev_tables[key]
+
+    # -- subclasses provide: _anchors_for_decode(), _activate(outputs) -> (locs, scores)
+    def candidates(self, outputs: tuple, conf_thresh: float = 0.01, top_k: int = 200) -> ops.Candidates:
+        locs, scores = self._activate(outputs)
+        anchors = self._table(self._anchors_for_decode(), scores.device)
+        return ops.select_decode(scores.contiguous(), locs.contiguous(), anchors, self.decode_mode,
+                                 self.class_begin, self.class_id_offset, conf_thresh, top_k)
+
+    def pre_predict(self, outputs: tuple, conf_thresh: float = 0.01, top_k: int = 200) -> tuple:
+        c = self.candidates(outputs, conf_thresh, top_k)
+        counts = c.counts.tolist()                      # the one device->host sync
+        dev = torch.device('cpu') if self.return_cpu else c.boxes.device
+        pb = [c.boxes[b, :n].to(dev) for b, n in enumerate(counts)]
+        ps = [c.scores[b, :n].to(dev) for b, n in enumerate(counts)]
+        pc = [c.class_ids[b, :n].to(dev) for b, n in enumerate(counts)]
+        return pb, ps, pc
+
+    def detect(self, outputs: tuple, image_metas: Sequence[dict], conf_thresh: float = 0.01, top_k: int = 200,
+               iou_thresh: float = 0.45):
+        """pre_predict + Predictor.run on the device.  Returns (rows_ids [N,2] i64, rows_vals [N,5] f64)
+        device tensors; nothing is synchronised except the final row count."""
+        c = self.candidates(outputs, conf_thresh, top_k)
+        keep, kc = ops.nms_candidates(c, iou_thresh)
+        dev = c.boxes.device
+        ids = torch.tensor([m['image_id'] for m in image_metas], dtype=torch.int64).to(dev, non_blocking=True)
+        hw = torch.tensor([[m['height'], m['width']] for m in image_metas], dtype=torch.int32).to(dev, non_blocking=True)
+        rows_ids, rows_vals, row_off = ops.pack_detections(c.boxes, c.scores, c.class_ids, keep, kc, ids, hw)
+        n = int(row_off[-1].item())
+        return rows_ids[:n], rows_vals[:n]
+
+
+class SSD300(_BoxOps):
+    """Box-ops of src/models/ssd300.py (default boxes :182-208, loss :210-297, pre_predict :339-384)."""
+
+    def __init__(self, num_classes: int):
+        super().__init__()
+        self.nc = num_classes + 1
+        self.dboxes = self._get_default_boxes()
+
+    def _get_default_boxes(self):
+        return A.ssd300_default_boxes()
+
+    def _anchors_for_decode(self):
+        return self.dboxes
+
+    def _activate(self, outputs):
+        out_locs, out_confs = outputs
+        return out_locs.detach(), F.softmax(out_confs, dim=-1).detach()
+
+    def assign(self, gt_bboxes: list, gt_labels: list, device, iou_thresh: float = 0.5, want_best=False):
+        gb, gl, off, total = ops.pack_gt(gt_bboxes, gt_labels, device)
+        return ops.assign_anchor(self._table(self.dboxes, device), gb, gl, off, total, ops.ASSIGN_CXCYWH,
+                                 iou_thresh, iou_thresh, want_best)
+
+    def loss(self, outputs: tuple, gt_bboxes: list, gt_labels: list, iou_thresh: float = 0.5, alpha: float = 1.0) -> dict:
+        out_locs, out_confs = outputs
+        B, P, C = out_confs.size()
+        target_locs, target_labels, _ = self.assign(gt_bboxes, gt_labels, out_locs.device, iou_thresh)
+        # Steps 2-5: src/models/ssd300.py:273-297
+        pos_mask = target_labels > 0
+        loss_neg = F.cross_entropy(out_confs.view(-1, C), target_labels.view(-1), reduction='none').view(B, -1)
+        loss_neg[pos_mask] = 0
+        loss_neg_rank = loss_neg.argsort(descending=True).argsort()
+        neg_mask = loss_neg_rank < 3 * pos_mask.sum(dim=1, keepdims=True)
+        N = pos_mask.sum()
+        loss_loc = F.smooth_l1_loss(out_locs[pos_mask], target_locs[pos_mask], reduction='sum') / N
+        sel = pos_mask + neg_mask
+        loss_conf = F.cross_entropy(out_confs[sel], target_labels[sel], reduction='sum') / N
+        return {'loss': loss_conf + alpha * loss_loc, 'loss_loc': loss_loc, 'loss_conf': loss_conf}
+
+
+class SSD512(SSD300):
+    """Box-ops of src/models/ssd512.py (24564 default boxes; loss / pre_predict inherited)."""
+
+    def _get_default_boxes(self):
+        return A.ssd512_default_boxes()
+
+
+class RetinaNet(_BoxOps):
+    """Box-ops of src/models/retinanet.py (prior boxes :120-139, loss :141-225, pre_predict :267-312).
+    The reference builds its priors lazily from the feature-map sizes of the first forward
+    (:116-117); here they are given up front (512 px: [64,32,16,8,4]; 800 px: [100,50,25,13,7])."""
+
+    def __init__(self, num_classes: int, f_k_list: Sequence[int] = (64, 32, 16, 8, 4)):
+        super().__init__()
+        self.nc = num_classes + 1
+        self.pboxes = self._get_prior_boxes(list(f_k_list))
+
+    def _get_prior_boxes(self, f_k_list):
+        return A.retinanet_prior_boxes(f_k_list)
+
+    def _anchors_for_decode(self):
+        return self.pboxes
+
+    def _activate(self, outputs):
+        out_locs, out_confs = outputs
+        return out_locs.detach(), F.softmax(out_confs, dim=-1).detach()
+
+    def assign(self, gt_bboxes, gt_labels, device, iou_threshs: tuple = (0.4, 0.5), want_best=False):
+        gb, gl, off, total = ops.pack_gt(gt_bboxes, gt_labels, device)
+        return ops.assign_anchor(self._table(self.pboxes, device), gb, gl, off, total, ops.ASSIGN_CXCYWH,
+                                 iou_threshs[0], iou_threshs[1], want_best)
+
+    def loss(self, outputs: tuple, gt_bboxes: list, gt_labels: list, iou_threshs: tuple = (0.4, 0.5)) -> dict:
+        out_locs, out_confs = outputs
+        target_locs, target_labels, _ = self.assign(gt_bboxes, gt_labels, out_locs.device, iou_threshs)
+        # Steps 2-5: src/models/retinanet.py:205-225
+        pos_mask = target_labels > 0
+        neg_mask = target_labels == 0
+        N = pos_mask.sum()
+        loss_loc = F.smooth_l1_loss(out_locs[pos_mask], target_locs[pos_mask], reduction='sum') / N
+        sel = pos_mask + neg_mask
+        loss_conf = focal_loss(out_confs[sel], target_labels[sel], reduction='sum') / N
+        return {'loss': loss_conf + loss_loc, 'loss_loc': loss_loc, 'loss_conf': loss_conf}
+
+
+class FCOS(_BoxOps):
+    """Box-ops of src/models/fcos.py (points/ranges :142-173, loss :175-279, pre_predict :299-343).
+    image_size is 512 in the reference (hard-coded at :152)."""
+    decode_mode = ops.DECODE_FCOS
+
+    def __init__(self, num_classes: int, f_k_list: Sequence[int] = (64, 32, 16, 8, 4), image_size: float = 512):
+        super().__init__()
+        self.nc = num_classes + 1
+        self.points = A.fcos_points(list(f_k_list), image_size)
+        self.regress_ranges = A.fcos_regress_ranges(list(f_k_list))
+
+    def _anchors_for_decode(self):
+        return self.points
+
+    def _activate(self, outputs):
+        out_locs, out_confs, out_cents = outputs
+        return out_locs.detach(), (F.softmax(out_confs, dim=-1) * out_cents.sigmoid()[..., None]).detach()
+
+    def assign(self, gt_bboxes, gt_labels, device):
+        gb, gl, off, total = ops.pack_gt(gt_bboxes, gt_labels, device)
+        return ops.assign_fcos(self._table(self.points, device), self._table(self.regress_ranges, device),
+                               gb, gl, off, total)
+
+    def loss(self, outputs: tuple, gt_bboxes: list, gt_labels: list) -> dict:
+        out_locs, out_confs, out_cents = outputs
+        target_locs, target_cents, target_labels, _ = self.assign(gt_bboxes, gt_labels, out_locs.device)
+        # Steps 2-5: src/models/fcos.py:254-279
+        pos_mask = target_labels > 0
+        neg_mask = target_labels == 0
+        N = pos_mask.sum()
+        loss_loc = iou_loss_with_distance(out_locs[pos_mask].exp(), target_locs[pos_mask], reduction='sum') / target_cents[pos_mask].sum()
+        loss_cent = F.binary_cross_entropy_with_logits(out_cents[pos_mask], target_cents[pos_mask], reduction='sum') / N
+        sel = pos_mask + neg_mask
+        loss_conf = focal_loss(out_confs[sel], target_labels[sel], reduction='sum') / N
+        return {'loss': loss_conf + loss_cent + loss_loc, 'loss_loc': loss_loc, 'loss_cent': loss_cent, 'loss_conf': loss_conf}
+
+
+class YoloV3(_BoxOps):
+    """Box-ops of src/models/yolov3.py (priors :107-125, loss :127-234, pre_predict :282-330).
+    pre_predict decodes with `_calc_coord(locs, pboxes[:, :4], pboxes[:, 4:])`, the evident intent
+    of :320 (which raises TypeError in the reference), and like the reference overwrites
+    out_locs[..., :2] with their sigmoid in place (:297)."""
+    decode_mode = ops.DECODE_YOLO
+    class_begin = 0
+    class_id_offset = 1      # emitted class id = column + 1 (yolov3.py:319)
+
+    def __init__(self, num_classes: int):
+        super().__init__()
+        self.nc = num_classes
+        self.pboxes = A.yolov3_prior_boxes()
+
+    def _anchors_for_decode(self):
+        return self.pboxes
+
+    def _activate(self, outputs):
+        out_locs, out_objs, out_confs = outputs
+        out_locs = out_locs.detach()
+        out_locs[..., :2] = out_locs[..., :2].sigmoid()
+        return out_locs, (out_confs.sigmoid() * out_objs.sigmoid()[..., None]).detach()
+
+    def assign(self, gt_bboxes, gt_labels, device, iou_thresh: float = 0.5, want_best=False):
+        gb, gl, off, total = ops.pack_gt(gt_bboxes, gt_labels, device)
+        return ops.assign_anchor(self._table(self.pboxes, device), gb, gl, off, total, ops.ASSIGN_YOLO,
+                                 iou_thresh, 1.0, want_best)
+
+    def loss(self, outputs: tuple, gt_bboxes: list, gt_labels: list, iou_thresh: float = 0.5) -> dict:
+        out_locs, out_objs, out_confs = outputs
+        target_locs, target_labels, _ = self.assign(gt_bboxes, gt_labels, out_locs.device, iou_thresh)
+        # Steps 2-5: src/models/yolov3.py:192-234
+        pos_mask = target_labels > 0
+        neg_mask = target_labels == 0
+        N = pos_mask.sum()
+        loss_loc = (F.binary_cross_entropy_with_logits(out_locs[pos_mask][..., :2], target_locs[pos_mask][..., :2], reduction='sum')
+                    + F.mse_loss(out_locs[pos_mask][..., 2:], target_locs[pos_mask][..., 2:], reduction='sum')) / N
+        loss_conf = F.binary_cross_entropy_with_logits(
+            out_confs[pos_mask], F.one_hot(target_labels[pos_mask] - 1, num_classes=self.nc).float(), reduction='sum') / N
+        sel = pos_mask + neg_mask
+        loss_obj = F.binary_cross_entropy_with_logits(out_objs[sel], pos_mask[sel].float(), reduction='sum') / N
+        return {'loss': loss_loc + loss_obj + loss_conf, 'loss_loc': loss_loc, 'loss_conf': loss_conf, 'loss_obj': loss_obj}
+
+
+MODELS = {'ssd300': SSD300, 'ssd512': SSD512, 'yolov3': YoloV3, 'retinanet': RetinaNet, 'fcos': FCOS}

@@ -1,0 +1,262 @@
+"""Operator layer over the detbox C ABI.
+
+Level 1 -- torchvision.ops-compatible signatures, the three symbols the reference
+imports (src/models/ssd300.py:5, src/utilities/predictor.py:3, src/datasets/dataset.py:2):
+    box_convert(boxes, in_fmt, out_fmt), box_iou(boxes1, boxes2),
+    batched_nms(boxes, scores, idxs, iou_threshold)
+Level 1b -- the fused batch operators the model classes in models.py are built on:
+    assign_anchor, assign_fcos, select_decode, nms_candidates, pack_detections
+
+Every operator runs on the GPU through libdetbox.so.  CPU tensors are accepted for
+the Level-1 functions (they are copied to the current GPU and the result is copied
+back, because the reference calls them on CPU tensors); nothing is ever computed on
+the host, and a missing library or GPU raises.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+FMT = {'xyxy': 0, 'xywh': 1, 'cxcywh': 2}
+ASSIGN_CXCYWH, ASSIGN_YOLO = 0, 1
+DECODE_CXCYWH, DECODE_YOLO, DECODE_FCOS = 0, 1, 2
+MAX_TOP_K = 4096
+NMS_MAX_SORT = 4096
+
+_workspaces = {}
+
+
+def _device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise _lib.DetboxError('no GPU visible: the detbox operators only run on a ROCm device')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _workspace(device, nbytes: int, tag: str) -> torch.Tensor:
+    """Grow-only scratch buffer per (device, operator); calls sharing it are ordered on the current stream."""
+    key = (device.index, tag)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None or t.numel() == 0 else t.data_ptr()
+
+
+# ------------------------------------------------------------------ Level 1
+
+def box_convert(boxes: torch.Tensor, in_fmt: str, out_fmt: str) -> torch.Tensor:
+    if in_fmt not in FMT or out_fmt not in FMT:
+        raise ValueError('Unsupported Bounding Box Conversions for given in_fmt and out_fmt')
+    src_device = boxes.device
+    dev = boxes.device if boxes.is_cuda else _device()
+    b = _f32(boxes, dev).reshape(-1, 4)
+    out = torch.empty_like(b)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().detbox_box_convert(_ptr(b), _ptr(out), b.shape[0], FMT[in_fmt], FMT[out_fmt], _stream(dev)),
+                   'detbox_box_convert')
+    return out.reshape(boxes.shape).to(src_device)
+
+
+def box_iou(boxes1: torch.Tensor, boxes2: torch.Tensor) -> torch.Tensor:
+    src_device = boxes1.device
+    dev = boxes1.device if boxes1.is_cuda else _device()
+    b1, b2 = _f32(boxes1, dev), _f32(boxes2, dev)
+    out = torch.empty((b1.shape[0], b2.shape[0]), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().detbox_box_iou(_ptr(b1), b1.shape[0], _ptr(b2), b2.shape[0], _ptr(out), _stream(dev)),
+                   'detbox_box_iou')
+    return out.to(src_device)
+
+
+def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, iou_threshold: float) -> torch.Tensor:
+    """torchvision.ops.batched_nms: NMS inside every class, kept indices in descending score order
+    (ties: lower index first)."""
+    src_device = boxes.device
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=src_device)
+    dev = boxes.device if boxes.is_cuda else _device()
+    with torch.cuda.device(dev):
+        b, s = _f32(boxes, dev), _f32(scores, dev)
+        cls = idxs.to(dev)
+        # group by class (stable: original order inside a class); long classes are pre-sorted by score
+        order = torch.argsort(cls, stable=True)
+        _, cnt = torch.unique_consecutive(cls[order], return_counts=True)
+        presorted = int(cnt.max().item()) > NMS_MAX_SORT
+        if presorted:
+            by_score = torch.argsort(s, descending=True, stable=True)
+            order = by_score[torch.argsort(cls[by_score], stable=True)]
+        S = cnt.numel()
+        seg = torch.zeros((1, S + 1), dtype=torch.int32, device=dev)
+        seg[0, 1:] = torch.cumsum(cnt, 0).to(torch.int32)
+        keep, kc = nms_segments(b[order].unsqueeze(0), s[order].unsqueeze(0), seg, iou_threshold,
+                                max_segment=int(cnt.max().item()), presorted=presorted)
+        k = int(kc[0].item())
+        if k < 0:
+            raise _lib.DetboxError('detbox_batched_nms_segments reported an over-long segment')
+        kept = order[keep[0, :k]]
+        # score ties between different classes: torchvision orders them by original index
+        kept = kept.sort().values
+        kept = kept[torch.argsort(s[kept], descending=True, stable=True)]
+        return kept.to(src_device)
+
+
+# ------------------------------------------------------------------ fused batch operators
+
+def pack_gt(gt_bboxes: Sequence[torch.Tensor], gt_labels: Sequence[torch.Tensor], device):
+    """List of per-image [G_i,4] / [G_i] tensors (the reference's collate contract,
+    src/datasets/dataset.py:88-100) -> packed [sum G,4] f32, [sum G] i64, offsets [B+1] i32 on `device`
+    with one host-to-device copy each."""
+    B = len(gt_bboxes)
+    counts = [int(b.shape[0]) for b in gt_bboxes]
+    off = torch.zeros(B + 1, dtype=torch.int32)
+    if B:
+        off[1:] = torch.cumsum(torch.tensor(counts, dtype=torch.int64), 0).to(torch.int32)
+    total = int(off[-1])
+    if total:
+        boxes = torch.cat([b.reshape(-1, 4).to(torch.float32) for b in gt_bboxes]).contiguous()
+        labels = torch.cat([l.reshape(-1).to(torch.int64) for l in gt_labels]).contiguous()
+    else:
+        boxes, labels = torch.zeros(0, 4), torch.zeros(0, dtype=torch.int64)
+    return boxes.to(device, non_blocking=True), labels.to(device, non_blocking=True), off.to(device, non_blocking=True), total
+
+
+def assign_anchor(anchors: torch.Tensor, gt_boxes: torch.Tensor, gt_labels: torch.Tensor, gt_offsets: torch.Tensor,
+                  total_gt: int, mode: int, thr_lo: float, thr_hi: float, want_best: bool = False):
+    """-> target_locs [B,P,4] f32, target_labels [B,P] i64, matched [B,P] i64 (, best_anchor [sum G] i64)."""
+    dev = anchors.device
+    B, P = gt_offsets.numel() - 1, anchors.shape[0]
+    locs = torch.empty((B, P, 4), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, P), dtype=torch.int64, device=dev)
+    matched = torch.empty((B, P), dtype=torch.int64, device=dev)
+    best = torch.empty((max(total_gt, 1),), dtype=torch.int64, device=dev) if want_best else None
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        ws = _workspace(dev, L.detbox_assign_anchor_workspace_bytes(total_gt), 'assign')
+        _lib.check(L.detbox_assign_anchor(mode, _ptr(anchors), P, _ptr(gt_boxes), _ptr(gt_labels), _ptr(gt_offsets),
+                                          B, total_gt, thr_lo, thr_hi, _ptr(locs), _ptr(labels), _ptr(matched),
+                                          _ptr(best), ws.data_ptr(), ws.numel(), _stream(dev)), 'detbox_assign_anchor')
+    if want_best:
+        return locs, labels, matched, best[:total_gt]
+    return locs, labels, matched
+
+
+def assign_fcos(points: torch.Tensor, ranges: torch.Tensor, gt_boxes, gt_labels, gt_offsets, total_gt: int):
+    """-> target_locs [B,P,4] (l,r,t,b), target_cents [B,P], target_labels [B,P], matched [B,P]."""
+    dev = points.device
+    B, P = gt_offsets.numel() - 1, points.shape[0]
+    locs = torch.empty((B, P, 4), dtype=torch.float32, device=dev)
+    cents = torch.empty((B, P), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, P), dtype=torch.int64, device=dev)
+    matched = torch.empty((B, P), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().detbox_assign_fcos(_ptr(points), _ptr(ranges), P, _ptr(gt_boxes), _ptr(gt_labels),
+                                                 _ptr(gt_offsets), B, total_gt, _ptr(locs), _ptr(cents), _ptr(labels),
+                                                 _ptr(matched), _stream(dev)), 'detbox_assign_fcos')
+    return locs, cents, labels, matched
+
+
+@dataclass
+class Candidates:
+    """Output of select_decode: image b owns rows [b, :counts[b]] of the [B, stride] arrays, grouped by
+    class (seg_offsets[b, s] .. seg_offsets[b, s+1]) and ordered by anchor index inside a class."""
+    boxes: torch.Tensor        # [B, stride, 4] xyxy
+    scores: torch.Tensor       # [B, stride]
+    class_ids: torch.Tensor    # [B, stride] int64
+    seg_offsets: torch.Tensor  # [B, S+1] int32
+    counts: torch.Tensor       # [B] int32
+    top_k: int
+
+
+def select_decode(scores: torch.Tensor, locs: torch.Tensor, anchors: torch.Tensor, decode_mode: int,
+                  class_begin: int, class_id_offset: int, conf_thresh: float, top_k: int,
+                  score_hi_hint: float = 1.0) -> Candidates:
+    dev = scores.device
+    B, P, C = scores.shape
+    S = C - class_begin
+    stride = S * top_k
+    out_boxes = torch.empty((B, stride, 4), dtype=torch.float32, device=dev)
+    out_scores = torch.empty((B, stride), dtype=torch.float32, device=dev)
+    out_cls = torch.empty((B, stride), dtype=torch.int64, device=dev)
+    seg = torch.empty((B, S + 1), dtype=torch.int32, device=dev)
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        ws = _workspace(dev, L.detbox_select_decode_workspace_bytes(B, P, C, class_begin, top_k), 'select')
+        _lib.check(L.detbox_select_decode(decode_mode, _ptr(scores), _ptr(locs), _ptr(anchors), B, P, C, class_begin,
+                                          class_id_offset, conf_thresh, top_k, score_hi_hint,
+                                          out_boxes.data_ptr(), out_scores.data_ptr(), out_cls.data_ptr(),
+                                          seg.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
+                   'detbox_select_decode')
+    return Candidates(out_boxes, out_scores, out_cls, seg, counts, top_k)
+
+
+def nms_segments(boxes: torch.Tensor, scores: torch.Tensor, seg_offsets: torch.Tensor, iou_threshold: float,
+                 max_segment: int = 0, presorted: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """boxes [B,stride,4], scores [B,stride], seg_offsets [B,S+1] -> keep [B,stride] i64, keep_counts [B] i32."""
+    dev = boxes.device
+    B, stride = scores.shape
+    S = seg_offsets.shape[1] - 1
+    keep = torch.empty((B, stride), dtype=torch.int64, device=dev)
+    kc = torch.empty((B,), dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        ws = _workspace(dev, L.detbox_batched_nms_segments_workspace_bytes(B, stride, S), 'nms')
+        _lib.check(L.detbox_batched_nms_segments(_ptr(boxes), _ptr(scores), _ptr(seg_offsets), B, stride, S,
+                                                 int(max_segment), float(iou_threshold), int(presorted),
+                                                 _ptr(keep), kc.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
+                   'detbox_batched_nms_segments')
+    return keep, kc
+
+
+def nms_candidates(c: Candidates, iou_threshold: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    return nms_segments(c.boxes, c.scores, c.seg_offsets, iou_threshold, max_segment=c.top_k, presorted=False)
+
+
+def pack_detections(boxes, scores, class_ids, keep, keep_counts, image_ids: torch.Tensor, image_sizes: torch.Tensor):
+    """-> rows_ids [B*stride,2] i64, rows_vals [B*stride,5] f64, row_offsets [B+1] i32 (rows beyond
+    row_offsets[B] are unused)."""
+    dev = boxes.device
+    B, stride = scores.shape
+    rows_ids = torch.empty((B * stride, 2), dtype=torch.int64, device=dev)
+    rows_vals = torch.empty((B * stride, 5), dtype=torch.float64, device=dev)
+    row_off = torch.empty((B + 1,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().detbox_pack_detections(_ptr(boxes), _ptr(scores), _ptr(class_ids), _ptr(keep),
+                                                     keep_counts.data_ptr(), image_ids.data_ptr(), image_sizes.data_ptr(),
+                                                     B, stride, rows_ids.data_ptr(), rows_vals.data_ptr(),
+                                                     row_off.data_ptr(), _stream(dev)), 'detbox_pack_detections')
+    return rows_ids, rows_vals, row_off
+
+
+# ------------------------------------------------------------------ per-kernel timing
+
+def profile_enable(on: bool = True):
+    _lib.check(_lib.lib().detbox_profile_enable(int(on)), 'detbox_profile_enable')
+
+
+def profile_reset():
+    _lib.check(_lib.lib().detbox_profile_reset(), 'detbox_profile_reset')
+
+
+def profile_read(name: str) -> Tuple[float, int]:
+    import ctypes
+    ms, n = ctypes.c_double(0.0), ctypes.c_int64(0)
+    _lib.check(_lib.lib().detbox_profile_read(name.encode(), ctypes.byref(ms), ctypes.byref(n)), 'detbox_profile_read')
+    return ms.value, n.value
