@@ -71,3 +71,13 @@ def rel_close(a: torch.Tensor, b: torch.Tensor, rtol=1e-5, atol=1e-6):
     both_nan = a.isnan() & b.isnan()
     ok = ((a - b).abs() <= atol + rtol * b.abs()) | both_nan | (a == b)
     return bool(ok.all())
+
+
+def box_close(a: torch.Tensor, b: torch.Tensor, rtol=1e-5):
+    """Decoded boxes: |a-b| <= rtol * (largest |coordinate| of that box).  A coordinate such as
+    `px - exp(l)` (FCOS) cancels, so its error is relative to the operands' magnitude -- which the
+    box's largest coordinate bounds within a factor 2 -- not to the (possibly tiny) difference."""
+    a, b = a.double(), b.double()
+    scale = b.abs().amax(dim=-1, keepdim=True).clamp(min=1e-30)
+    ok = ((a - b).abs() <= rtol * scale) | (a == b) | (a.isnan() & b.isnan())
+    return bool(ok.all())

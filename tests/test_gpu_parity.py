@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import head_outputs, load, predict_inputs, rel_close, sha, split, unpack_gt
+from helpers import box_close, head_outputs, load, predict_inputs, rel_close, sha, split, unpack_gt
 
 pytestmark = pytest.mark.gpu
 
@@ -239,7 +239,7 @@ def check_select(got, want):
         assert pc[b].shape == wc[b].shape, (b, pc[b].shape, wc[b].shape)
         assert torch.equal(pc[b], wc[b])
         assert torch.equal(ps[b], ws[b])           # scores are copied, so bit-exact
-        assert rel_close(pb[b], wb[b], RTOL)
+        assert box_close(pb[b], wb[b], RTOL)
 
 
 PREDICT = [('retinanet_small', 'retinanet_small_pboxes'), ('ssd300', 'ssd300_dboxes'),
@@ -264,7 +264,7 @@ def test_select_nms_pack_match_golden(D, oracle, dev, name, table):
     assert [b.shape[0] for b in pb] == counts
     assert np.array_equal(torch.cat(pc).numpy(), z['class_ids'].astype(np.int64))
     assert np.array_equal(torch.cat(ps).numpy(), z['scores'])
-    assert rel_close(torch.cat(pb), torch.from_numpy(z['bboxes']), RTOL)
+    assert box_close(torch.cat(pb), torch.from_numpy(z['bboxes']), RTOL)
     # NMS on the reference's own candidate boxes (bit-identical inputs -> bit-exact keep lists)
     gold_b = split(torch.from_numpy(z['bboxes']), counts)
     stride = c.boxes.shape[1]
