@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""Benchmark of the detection box-ops hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--regime dense|sparse]
+
+One "step" = one pass of the whole path over one batch of synthetic head outputs that already sit
+in HBM: target assignment (train side) + activation + threshold/top-k/decode + per-class NMS +
+result rows (inference side); with N > 1 ranks also the all-gather of the result rows.  Each rank
+owns its own images (weak scaling, image-sharded); `value` = images of all ranks / wall time.
+
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel of the step with HIP events
+recorded on its launch stream during the timed steps; `cpu_baseline` times the CPU oracle (the
+loop-faithful restatement of the reference path) on a small sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import object_detection_amd as D  # noqa: E402
+from object_detection_amd import ops  # noqa: E402
+from object_detection_amd.dist import gather_detections  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, spec
+
+WORKLOADS = {
+    # name: (family, ctor, B, C_stored, top_k, coco_like, gt_fmt, gt_scale)
+    'retinanet800': dict(family='retina', B=16, C=81, top_k=1000, coco=True, fmt='cxcywh', scale=1.0,
+                         make=lambda: D.RetinaNet(80, [100, 50, 25, 13, 7])),
+    'ssd300': dict(family='ssd', B=8, C=21, top_k=200, coco=False, fmt='cxcywh', scale=1.0, make=lambda: D.SSD300(20)),
+    'ssd300_b512': dict(family='ssd', B=512, C=21, top_k=200, coco=False, fmt='cxcywh', scale=1.0, make=lambda: D.SSD300(20)),
+    'fcos800': dict(family='fcos', B=16, C=81, top_k=200, coco=True, fmt='cxcywh', scale=512.0,
+                    make=lambda: D.FCOS(80, [100, 50, 25, 13, 7])),
+    'yolov3': dict(family='yolo', B=64, C=20, top_k=200, coco=False, fmt='xywh', scale=1.0, make=lambda: D.YoloV3(20)),
+}
+
+
+def synth_gt(i, num_fg, coco_like, fmt, scale):
+    """Same recipe as the oracle's synth_gt (GT seed 1000+i); duplicated here so that the timed
+    product path imports nothing from oracle/."""
+    g = torch.Generator().manual_seed(1000 + i)
+    G = 1 + (i % (64 if coco_like else 16))
+    c = 0.15 + 0.70 * torch.rand(G, 2, generator=g)
+    wh = 0.04 + 0.46 * torch.rand(G, 2, generator=g)
+    boxes = torch.cat([c, wh], dim=1) if fmt != 'xywh' else torch.cat([c - wh / 2, wh], dim=1)
+    labels = torch.randint(1, num_fg + 1, (G,), generator=g)
+    return boxes * scale, labels
+
+
+def synth_head(i, P, C, family, regime):
+    """Head outputs of image i (seed 2000+i): locs ~ N(0,1), logits ~ N(0,1) (dense) or with the
+    background column +8 / objectness -6 (sparse)."""
+    g = torch.Generator().manual_seed(2000 + i)
+    locs = torch.randn(P, 4, generator=g)
+    confs = torch.randn(P, C, generator=g)
+    ext = torch.randn(P, generator=g) if family in ('fcos', 'yolo') else None
+    if regime == 'sparse':
+        if family == 'yolo':
+            ext -= 6.0
+        else:
+            confs[:, 0] += 8.0
+    return locs, confs, ext
+
+
+class Workload:
+    def __init__(self, name, regime, rank, dev):
+        w = WORKLOADS[name]
+        self.name, self.regime, self.w, self.dev = name, regime, w, dev
+        self.model = w['make']()
+        m = self.model
+        self.anchors_cpu = m._anchors_for_decode()
+        self.P = self.anchors_cpu.shape[0]
+        self.B, self.C, self.top_k = w['B'], w['C'], w['top_k']
+        self.images = list(range(rank * self.B, (rank + 1) * self.B))
+        num_fg = self.C - 1 if w['family'] != 'yolo' else self.C
+        gts = [synth_gt(i, num_fg, w['coco'], w['fmt'], w['scale']) for i in self.images]
+        self.gt_b, self.gt_l = [g[0] for g in gts], [g[1] for g in gts]
+        self.gtb, self.gtl, self.goff, self.total_gt = ops.pack_gt(self.gt_b, self.gt_l, dev)
+        locs, confs, ext = [], [], []
+        for i in self.images:
+            l, c, e = synth_head(i, self.P, self.C, w['family'], regime)
+            locs.append(l); confs.append(c); ext.append(e)
+        self.locs_cpu, self.confs_cpu = torch.stack(locs), torch.stack(confs)
+        self.ext_cpu = torch.stack(ext) if ext[0] is not None else None
+        self.locs, self.confs = self.locs_cpu.to(dev), self.confs_cpu.to(dev)
+        self.ext = self.ext_cpu.to(dev) if self.ext_cpu is not None else None
+        self.metas = [{'image_id': i, 'height': 480, 'width': 640} for i in self.images]
+        self.ids = torch.tensor([m_['image_id'] for m_ in self.metas], dtype=torch.int64, device=dev)
+        self.hw = torch.tensor([[m_['height'], m_['width']] for m_ in self.metas], dtype=torch.int32, device=dev)
+        self.anchors = m._table(self.anchors_cpu, dev)
+        if w['family'] == 'fcos':
+            self.ranges = m._table(m.regress_ranges, dev)
+        self.act_events = []
+
+    def outputs(self):
+        f = self.w['family']
+        if f == 'fcos':
+            return (self.locs, self.confs, self.ext)
+        if f == 'yolo':
+            return (self.locs.clone(), self.ext, self.confs)     # pre_predict overwrites locs[..., :2]
+        return (self.locs, self.confs)
+
+    def assign(self):
+        f = self.w['family']
+        if f == 'ssd':
+            return ops.assign_anchor(self.anchors, self.gtb, self.gtl, self.goff, self.total_gt, ops.ASSIGN_CXCYWH, 0.5, 0.5)
+        if f == 'retina':
+            return ops.assign_anchor(self.anchors, self.gtb, self.gtl, self.goff, self.total_gt, ops.ASSIGN_CXCYWH, 0.4, 0.5)
+        if f == 'yolo':
+            return ops.assign_anchor(self.anchors, self.gtb, self.gtl, self.goff, self.total_gt, ops.ASSIGN_YOLO, 0.5, 1.0)
+        return ops.assign_fcos(self.anchors, self.ranges, self.gtb, self.gtl, self.goff, self.total_gt)
+
+    def step(self, world, record_act=False):
+        """The whole path once.  Returns device tensors; no host synchronisation for world == 1."""
+        targets = self.assign()
+        m = self.model
+        if record_act:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        locs, scores = m._activate(self.outputs())
+        if record_act:
+            e1.record()
+            self.act_events.append((e0, e1))
+        c = ops.select_decode(scores, locs, self.anchors, m.decode_mode, m.class_begin, m.class_id_offset, 0.01, self.top_k)
+        keep, kc = ops.nms_candidates(c, 0.45)
+        rows_ids, rows_vals, row_off = ops.pack_detections(c.boxes, c.scores, c.class_ids, keep, kc, self.ids, self.hw)
+        if world > 1:
+            n = int(row_off[-1].item())
+            rows_ids, rows_vals = gather_detections(rows_ids[:n], rows_vals[:n])
+        return targets, c, kc, rows_ids, rows_vals, row_off
+
+
+def cpu_baseline(wl, n_img):
+    """The CPU oracle (loop-faithful restatement of the reference: per-image Python loop, per-class
+    double argsort, greedy CPU NMS, per-detection dict loop) on the first n_img images of rank 0."""
+    from oracle import boxops_oracle as O
+    f = wl.w['family']
+    gb, gl = wl.gt_b[:n_img], wl.gt_l[:n_img]
+    locs, confs = wl.locs_cpu[:n_img].clone(), wl.confs_cpu[:n_img].clone()
+    ext = wl.ext_cpu[:n_img].clone() if wl.ext_cpu is not None else None
+    a = wl.anchors_cpu
+    t0 = time.perf_counter()
+    if f == 'ssd':
+        O.assign_ssd(a, gb, gl)
+        pb, ps, pc = O.pre_predict_softmax(locs, confs, a, 0.01, wl.top_k)
+    elif f == 'retina':
+        O.assign_retinanet(a, gb, gl)
+        pb, ps, pc = O.pre_predict_softmax(locs, confs, a, 0.01, wl.top_k)
+    elif f == 'fcos':
+        O.assign_fcos(a, wl.model.regress_ranges, gb, gl)
+        pb, ps, pc = O.pre_predict_fcos(locs, confs, ext, a, 0.01, wl.top_k)
+    else:
+        O.assign_yolov3(a, gb, gl)
+        pb, ps, pc = O.pre_predict_yolov3(locs, ext, confs, a, 0.01, wl.top_k)
+    res = O.predictor_run(wl.metas[:n_img], pb, ps, pc, 0.45)
+    dt = time.perf_counter() - t0
+    return n_img / dt, dt, len(res)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='retinanet800', choices=sorted(WORKLOADS))
+    ap.add_argument('--regime', default='dense', choices=['dense', 'sparse'])
+    ap.add_argument('--cpu-images', type=int, default=-1, help='images in the CPU baseline sample (0 = skip)')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and rank == 0:
+        print(f'[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE', file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    wl = Workload(args.workload, args.regime, rank, dev)
+    B, P, C = wl.B, wl.P, wl.C
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(max(args.warmup, 1)):
+        out = wl.step(world)
+    torch.cuda.synchronize()
+    _, c, kc, _, _, row_off = out
+    n_cand = float(c.counts.sum().item()) / B
+    n_keep = float(kc.clamp(min=0).sum().item()) / B
+    if bool((kc < 0).any().item()):
+        raise RuntimeError('NMS reported an error flag')
+
+    ops.profile_reset()
+    ops.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step(world, record_act=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        names = ['assign_anchor', 'assign_fixup', 'assign_fcos', 'score_hist', 'select_kth', 'select_refine',
+                 'select_emit', 'select_finalize', 'nms_segments', 'nms_scan', 'nms_merge', 'pack_detections']
+        kern = {}
+        for nm in names:
+            ms, n = ops.profile_read(nm)
+            if n:
+                kern[nm] = dict(total_ms=ms, launches=n, avg_us=1e3 * ms / n)
+        act_ms = sum(a.elapsed_time(b) for a, b in wl.act_events)
+        kern['activation(torch)'] = dict(total_ms=act_ms, launches=len(wl.act_events), avg_us=1e3 * act_ms / max(len(wl.act_events), 1))
+        G_mean = wl.total_gt / B
+        score_bytes = 4.0 * B * P * C
+        alg_bytes = {      # algorithmic bytes per launch (whole batch of this rank)
+            'score_hist': score_bytes, 'select_emit': score_bytes,
+            'assign_anchor': B * (48.0 * P + 24.0 * G_mean), 'assign_fcos': B * (52.0 * P + 24.0 * G_mean),
+            'nms_segments': B * (28.0 * n_cand + 8.0 * n_keep),
+            'select_finalize': B * (28.0 * n_cand + 32.0 * n_cand),
+        }
+        ours = {k: v for k, v in kern.items() if k in alg_bytes}
+        dom = max(ours, key=lambda k: ours[k]['total_ms'])
+        dur_s = ours[dom]['avg_us'] * 1e-6
+        achieved = alg_bytes[dom] / dur_s / 1e9
+        roofline = dict(kernel=dom, bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
+                        frac=achieved / HBM_PEAK_GBS, traffic=None, avg_us=ours[dom]['avg_us'],
+                        algorithmic_bytes=alg_bytes[dom])
+        anchor_bytes = {'fcos': 8, 'yolo': 20}.get(wl.w['family'], 16)
+        bytes_img = ((52.0 if wl.w['family'] == 'fcos' else 48.0) * P + 24.0 * G_mean
+                     + 4.0 * P * C + 16.0 * P + anchor_bytes * P + (4.0 * P if wl.ext is not None else 0.0) + 28.0 * n_cand
+                     + 28.0 * n_cand + 8.0 * n_keep)
+        ips = world * B * args.steps / elapsed
+        n_cpu = args.cpu_images if args.cpu_images >= 0 else (2 if P > 50000 else 8)
+        cpu = None
+        if world == 1 and n_cpu > 0:
+            n_cpu = min(n_cpu, B)
+            v, dt, nres = cpu_baseline(wl, n_cpu)
+            cpu = dict(value=v, unit='images/s', cores=torch.get_num_threads(), kind='port',
+                       sample=f'{n_cpu} image(s) of the same workload through the CPU oracle '
+                              f'(assign + loop-faithful pre_predict + greedy NMS + dict loop), {dt:.1f} s, {nres} detections')
+        line = {
+            'metric': 'images/sec assign+decode+NMS', 'value': ips, 'unit': 'images/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{args.workload} {args.regime}: B={B}/GPU P={P} C={C} top_k={wl.top_k} conf>0.01 nms=0.45',
+                       'images_per_gpu': B, 'global_batch': world * B, 'candidates_per_image': n_cand,
+                       'kept_per_image': n_keep, 'gt_per_image': G_mean, 'parallelism': f'image-sharded x{world}'},
+            'roofline': roofline,
+            'cpu_baseline': cpu,
+            'pipeline': {'algorithmic_bytes_per_image': bytes_img,
+                         'hbm_frac_whole_step': bytes_img * ips / world / (HBM_PEAK_GBS * 1e9)},
+            'kernels_avg_us': {k: round(v['avg_us'], 2) for k, v in kern.items()},
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

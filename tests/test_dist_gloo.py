@@ -1,0 +1,72 @@
+"""CPU, world_size 2 over gloo: image sharding and the all-gather of result rows reproduce the
+single-process result order."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _fake_rows(image_index: int):
+    """Deterministic stand-in for one image's detections (row count varies, may be zero)."""
+    g = torch.Generator().manual_seed(100 + image_index)
+    n = int(torch.randint(0, 7, (1,), generator=g))
+    ids = torch.stack([torch.full((n,), 1000 + image_index, dtype=torch.int64),
+                       torch.randint(1, 21, (n,), generator=g)], dim=1)
+    vals = torch.rand(n, 5, generator=g, dtype=torch.float64)
+    return ids, vals
+
+
+def _worker(rank, world, port, num_images, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from object_detection_amd.dist import gather_detections, shard_range
+    lo, hi = shard_range(num_images, rank, world)
+    rows = [_fake_rows(i) for i in range(lo, hi)]
+    ids = torch.cat([r[0] for r in rows]) if rows else torch.zeros(0, 2, dtype=torch.int64)
+    vals = torch.cat([r[1] for r in rows]) if rows else torch.zeros(0, 5, dtype=torch.float64)
+    gids, gvals = gather_detections(ids, vals)
+    q.put((rank, gids, gvals))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(num_images, world=2):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, num_images, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rows = [_fake_rows(i) for i in range(num_images)]
+    want_ids = torch.cat([r[0] for r in rows]) if rows else torch.zeros(0, 2, dtype=torch.int64)
+    want_vals = torch.cat([r[1] for r in rows]) if rows else torch.zeros(0, 5, dtype=torch.float64)
+    for _, gids, gvals in got:
+        assert torch.equal(gids, want_ids) and torch.equal(gvals, want_vals)
+
+
+def test_shard_ranges_cover_batch():
+    from object_detection_amd.dist import shard_range
+    for n in (0, 1, 7, 16, 513):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_gather_two_ranks_even_and_ragged():
+    _run(8)
+    _run(5)       # uneven shards (3 + 2 images)
+    _run(1)       # one rank has no image at all
