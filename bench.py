@@ -96,7 +96,6 @@ class Workload:
         self.anchors = m._table(self.anchors_cpu, dev)
         if w['family'] == 'fcos':
             self.ranges = m._table(m.regress_ranges, dev)
-        self.act_events = []
 
     def outputs(self):
         f = self.w['family']
@@ -116,18 +115,11 @@ class Workload:
             return ops.assign_anchor(self.anchors, self.gtb, self.gtl, self.goff, self.total_gt, ops.ASSIGN_YOLO, 0.5, 1.0)
         return ops.assign_fcos(self.anchors, self.ranges, self.gtb, self.gtl, self.goff, self.total_gt)
 
-    def step(self, world, record_act=False):
+    def step(self, world):
         """The whole path once.  Returns device tensors; no host synchronisation for world == 1."""
         targets = self.assign()
         m = self.model
-        if record_act:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        locs, scores = m._activate(self.outputs())
-        if record_act:
-            e1.record()
-            self.act_events.append((e0, e1))
-        c = ops.select_decode(scores, locs, self.anchors, m.decode_mode, m.class_begin, m.class_id_offset, 0.01, self.top_k)
+        c = m.candidates(self.outputs(), 0.01, self.top_k)      # activation fused into the selection pass
         keep, kc = ops.nms_candidates(c, 0.45)
         rows_ids, rows_vals, row_off = ops.pack_detections(c.boxes, c.scores, c.class_ids, keep, kc, self.ids, self.hw)
         if world > 1:
@@ -208,7 +200,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        wl.step(world, record_act=True)
+        wl.step(world)
     barrier()
     elapsed = time.perf_counter() - t0
     ops.profile_enable(False)
@@ -218,19 +210,18 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        names = ['assign_anchor', 'assign_fixup', 'assign_fcos', 'score_hist', 'select_kth', 'select_refine',
-                 'select_emit', 'select_finalize', 'nms_segments', 'nms_scan', 'nms_merge', 'pack_detections']
+        names = ['assign_anchor', 'assign_fixup', 'assign_fcos', 'select_sample', 'select_plan', 'select_scan',
+                 'select_check', 'select_materialize', 'score_hist', 'select_kth', 'select_refine', 'select_emit',
+                 'select_finalize', 'nms_segments', 'nms_scan', 'nms_merge', 'pack_detections']
         kern = {}
         for nm in names:
             ms, n = ops.profile_read(nm)
             if n:
                 kern[nm] = dict(total_ms=ms, launches=n, avg_us=1e3 * ms / n)
-        act_ms = sum(a.elapsed_time(b) for a, b in wl.act_events)
-        kern['activation(torch)'] = dict(total_ms=act_ms, launches=len(wl.act_events), avg_us=1e3 * act_ms / max(len(wl.act_events), 1))
         G_mean = wl.total_gt / B
         score_bytes = 4.0 * B * P * C
         alg_bytes = {      # algorithmic bytes per launch (whole batch of this rank)
-            'score_hist': score_bytes, 'select_emit': score_bytes,
+            'select_scan': score_bytes, 'score_hist': score_bytes, 'select_emit': score_bytes,
             'assign_anchor': B * (48.0 * P + 24.0 * G_mean), 'assign_fcos': B * (52.0 * P + 24.0 * G_mean),
             'nms_segments': B * (28.0 * n_cand + 8.0 * n_keep),
             'select_finalize': B * (28.0 * n_cand + 32.0 * n_cand),

@@ -98,24 +98,40 @@ int detbox_assign_fcos(const float *points, const float *regress_ranges, int64_t
                        float *target_locs, float *target_cents, int64_t *target_labels, int64_t *matched,
                        void *stream);
 
-/* ---- inference: threshold + exact top-k + decode ----------------------------------------- */
+/* ---- inference: activation + threshold + exact top-k + decode ---------------------------- */
 
-/* Replaces the per-image, per-class loop of every pre_predict (src/models/ssd300.py:364-382,
- * src/models/retinanet.py:292-310, src/models/fcos.py:324-341, src/models/yolov3.py:311-329):
- * for every image b and class c in [class_begin, C) keep the anchors with
- *     scores[b,p,c] > conf_thresh  and  descending rank of scores[b,:,c] < top_k
+/* activations applied to the head output before the threshold */
+#define DETBOX_ACT_NONE 0            /* input already holds the scores                                  */
+#define DETBOX_ACT_SOFTMAX 1         /* softmax over C                (ssd300.py:354, retinanet.py:282) */
+#define DETBOX_ACT_SOFTMAX_SIGMOID 2 /* softmax over C * sigmoid(extra[b,p])             (fcos.py:314)  */
+#define DETBOX_ACT_SIGMOID_SIGMOID 3 /* sigmoid * sigmoid(extra[b,p])                (yolov3.py:298-300) */
+
+/* Writes the activated scores out[B,P,C] of in[B,P,C] (extra [B,P] for the two activations that use
+ * it).  The arithmetic is the one detbox_select_decode applies internally, bit for bit, so a caller
+ * (or a test) can see exactly the scores the selection ranked.  Limit: C <= 512. */
+int detbox_activate_scores(int activation, const float *in, const float *extra, int64_t B, int64_t P, int64_t C,
+                           float *out, void *stream);
+
+/* Replaces the activation and the per-image, per-class loop of every pre_predict
+ * (src/models/ssd300.py:354-382, src/models/retinanet.py:282-310, src/models/fcos.py:314-341,
+ * src/models/yolov3.py:298-329): for every image b and class c in [class_begin, C) keep the anchors with
+ *     score[b,p,c] > conf_thresh  and  descending rank of score[b,:,c] < top_k
  * (ties at the boundary: lower anchor index wins), decode their boxes to xyxy and emit them
  * class-major, anchor-index ascending.
- *   scores        [B,P,C] activated scores; locs [B,P,4]; anchors per decode_mode
+ *   scores        [B,P,C] head output (logits, or scores when activation == DETBOX_ACT_NONE);
+ *                 extra [B,P] or NULL; locs [B,P,4]; anchors per decode_mode
  *   score_hi_hint upper end of the expected score range (1.0 for probabilities).  Speed only.
  *   out_*         image b owns rows b*stride .. b*stride+out_counts[b]-1, stride = (C-class_begin)*top_k;
  *                 out_boxes [B*stride,4], out_scores [B*stride], out_class_ids [B*stride]
  *                 (= c + class_id_offset)
  *   out_seg_offsets [B, (C-class_begin)+1]: class segment boundaries inside image b's rows
  *   out_counts    [B]
- * Limit: 1 <= top_k <= DETBOX_MAX_TOP_K. */
-size_t detbox_select_decode_workspace_bytes(int64_t B, int64_t P, int64_t C, int class_begin, int top_k);
-int detbox_select_decode(int decode_mode, const float *scores, const float *locs, const float *anchors,
+ * Limits: 1 <= top_k <= DETBOX_MAX_TOP_K, C <= 256, C - class_begin <= 128.  With a fused activation
+ * the workspace also reserves B*P*C floats that only the exact fallback path touches. */
+size_t detbox_select_decode_workspace_bytes(int64_t B, int64_t P, int64_t C, int class_begin, int top_k,
+                                            int activation);
+int detbox_select_decode(int decode_mode, int activation, const float *scores, const float *extra,
+                         const float *locs, const float *anchors,
                          int64_t B, int64_t P, int64_t C, int class_begin, int class_id_offset,
                          float conf_thresh, int top_k, float score_hi_hint,
                          float *out_boxes, float *out_scores, int64_t *out_class_ids,
@@ -158,7 +174,8 @@ int detbox_pack_detections(const float *boxes, const float *scores, const int64_
 /* While enabled, every kernel launch is bracketed by hipEvents recorded on its stream.
  * detbox_profile_read synchronises those events and returns the accumulated time and launch
  * count of the kernel called `name`; reset drops all samples.  Kernel names: "box_convert",
- * "box_iou", "assign_anchor", "assign_fixup", "assign_fcos", "score_hist", "select_kth",
+ * "box_iou", "assign_anchor", "assign_fixup", "assign_fcos", "activate_scores", "select_sample",
+ * "select_plan", "select_scan", "select_check", "select_materialize", "score_hist", "select_kth",
  * "select_refine", "select_emit", "select_finalize", "nms_segments", "nms_scan", "nms_merge",
  * "nms_write", "pack_detections". */
 int detbox_profile_enable(int on);

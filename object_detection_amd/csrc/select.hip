@@ -1,53 +1,65 @@
-// Inference-time candidate selection: score threshold + exact per-class top-k +
-// box decode, for a whole batch, replacing the per-image / per-class Python loop
-// of every pre_predict (src/models/ssd300.py:364-382, src/models/retinanet.py:292-310,
-// src/models/fcos.py:324-341, src/models/yolov3.py:311-329) and their
+// Inference-time candidate selection: activation + score threshold + exact per-class
+// top-k + box decode for a whole batch, replacing the per-image / per-class Python loop
+// of every pre_predict (src/models/ssd300.py:354-382, src/models/retinanet.py:282-310,
+// src/models/fcos.py:314-341, src/models/yolov3.py:297-329) and their
 // `argsort(descending=True).argsort() < top_k` rank trick (ssd300.py:370).
 //
-// The score tensor [B,P,C] (class innermost) is streamed twice, fully coalesced:
-//   score_hist      per-(image,class) 256-bin histogram of the scores above the
-//                   threshold (bins are equal slices of the monotone uint32 image
-//                   of fp32 between the threshold and score_hi_hint), built in
-//                   LDS per anchor tile and merged with global atomics;
-//   select_kth      per (image,class): the bin holding the top_k-th score, the
-//                   selection rule, the class segment offsets of the output;
-//   select_refine   only for (image,class) pairs whose boundary bin is too full
-//                   (massive ties): exact radix search of the 64-bit cut-off key;
-//   select_emit     second pass: scores at or above the boundary bin are appended
-//                   (unordered) to a small per-(image,class) staging list;
-//   select_finalize per (image,class): bitonic sort of the staged keys in LDS,
-//                   exact cut at top_k, re-sort by anchor index, decode, write.
+// The head output [B,P,C] (class innermost) is streamed from HBM ONCE on the fast path:
+//   select_sample   activates every sample_rate-th 64-anchor sub-tile and builds a 256-bin
+//                   histogram per (image,class) of the sampled scores above the threshold;
+//   select_plan     per (image,class): a score t_lo low enough that, with overwhelming
+//                   probability, at least top_k scores lie at or above it (or "stage all");
+//   select_scan     the one full pass: 64 anchors x C logits are staged in LDS (coalesced
+//                   16-byte loads), four lanes share an anchor row for the soft-max, every
+//                   score >= t_lo is appended to a block-local LDS list and flushed with ONE
+//                   global atomic per (block, class) into that pair's staging list;
+//   select_check    verifies the guess (enough staged, not too many); pairs that fail are
+//                   handed to the exact two-pass fallback below and a flag is raised;
+//   select_finalize per (image,class): exact top_k of the staged keys by radix select in LDS,
+//                   ordering by anchor index through an LDS bitmap + popcount scan, decode.
+// Fallback (kernels exit at once unless the flag is up; also the only path for tiny P):
+//   select_materialize (fused activation only) writes the activated scores to the workspace,
+//   score_hist / select_kth / select_refine / select_emit find the exact boundary bin (or, on
+//   massive ties, the exact 64-bit cut-off key) from a full histogram and re-stage.
 //
-// Selection key: K = ((okey(score) - okey(thr)) << 32) | (0xffffffff - anchor), so
-// "larger K" means higher score, then lower anchor index: boundary ties go to the
-// lower anchor index, and all keys of one class are distinct.
+// Selection key: K = ((okey(score) - okey(thr)) << 32) | (0xffffffff - anchor): larger K
+// means higher score, then lower anchor index (boundary ties go to the lower anchor), and
+// all keys of one class are distinct.
 #include "detbox_internal.h"
 
+#include <cmath>
 #include <cstring>
 
 using namespace detbox;
 
 namespace {
 
-constexpr int NB = 256;             // histogram bins per (image, class)
-constexpr int PASS_BLOCK = 512;
-constexpr int MAX_SEL_CLASSES = 128;  // LDS histogram: classes * NB/2 words
+constexpr int NB = 256;               // histogram bins per (image, class)
+constexpr int PASS_BLOCK = 512;       // fallback streaming passes
+constexpr int MAX_SEL_CLASSES = 128;  // LDS tables are sized for this many selected classes
 constexpr int MAX_TILE_ANCHORS = 16384;
+constexpr int SUB_ROWS = 64;          // anchors per LDS sub-tile (4 lanes per anchor row)
+constexpr int SCAN_BLOCK = 256;
+constexpr int LCAP = 1024;            // block-local candidate list (entries)
+constexpr int SAMPLE_SUBS = 8;        // sampled sub-tiles per block of select_sample
+constexpr int BITMAP_MAX_WORDS = 4096;  // finalize orders by anchor through a P-bit LDS bitmap up to this
 
-enum { RULE_ALL = 0, RULE_HIST = 1, RULE_EXACT = 2 };
+enum { ACT_NONE = 0, ACT_SOFTMAX = 1, ACT_SOFTMAX_SIGMOID = 2, ACT_SIGMOID_SIGMOID = 3 };
+enum { RULE_ALL = 0, RULE_HIST = 1, RULE_EXACT = 2, RULE_STAGED = 3, RULE_PENDING = 4 };
 
 struct SelRule {
     uint32_t mode;      // RULE_*
-    uint32_t beta;      // RULE_HIST: boundary bin (bins above are certain)
-    uint32_t n_above;   // scores in bins above beta
+    uint32_t beta;      // RULE_HIST: boundary bin; RULE_STAGED: 1 when every score above the threshold is staged
+    uint32_t n_above;   // RULE_HIST/EXACT: scores in bins above beta
     uint32_t n_sel;     // rows this (image,class) will output
     unsigned long long cutoff;  // RULE_EXACT: keep K >= cutoff
-    float min_score;    // cheap reject: nothing below this can be selected
+    float min_score;    // nothing below this is staged
     uint32_t pad;
 };
 
 struct SelParams {
     int P, C, cb, Cs, top_k, cap, shift, tile_anchors;
+    int use_sample, sample_rate, sample_m, subs_per_block, n_sub, tile_floats;
     float thr;
     uint32_t key_thr;
 };
@@ -58,6 +70,300 @@ __device__ inline uint32_t bin_of(uint32_t d, int shift) {
     uint32_t b = d >> shift;
     return b > (uint32_t)(NB - 1) ? (uint32_t)(NB - 1) : b;
 }
+
+__device__ inline float score_from_d(uint32_t key_thr, unsigned long long d) {
+    unsigned long long k = (unsigned long long)key_thr + d;
+    if (k > 0xffffffffull) k = 0xffffffffull;
+    return __uint_as_float(bits_from_okey((uint32_t)k));
+}
+
+__device__ inline unsigned long long make_key(float s, uint32_t key_thr, uint32_t p) {
+    return ((unsigned long long)(okey(s) - key_thr) << 32) | (unsigned long long)(0xffffffffu - p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Activation of one sub-tile: rows x C head outputs -> scores, four lanes per anchor row.
+// ---------------------------------------------------------------------------------------------
+
+__device__ inline float quad_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1));
+    return fmaxf(v, __shfl_xor(v, 2));
+}
+__device__ inline float quad_sum(float v) {
+    v += __shfl_xor(v, 1);
+    return v + __shfl_xor(v, 2);
+}
+__device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Stages rows [row_base, row_base+rows) x C of `in` into LDS with coalesced 16-byte loads (the
+// LDS image starts `shift` floats in, so that every load and LDS store is 16-byte aligned), applies
+// the activation and calls f(score, class, local_row) for every element.  Block = SCAN_BLOCK threads.
+//   ACT_SOFTMAX          score = exp(x - max) / sum                    (ssd300.py:354, retinanet.py:282)
+//   ACT_SOFTMAX_SIGMOID  score = softmax(x) * sigmoid(extra[row])      (fcos.py:314)
+//   ACT_SIGMOID_SIGMOID  score = sigmoid(x) * sigmoid(extra[row])      (yolov3.py:298-300)
+template <int ACT, typename F>
+__device__ inline void activate_subtile(const float *__restrict__ in, const float *__restrict__ extra,
+                                        long long row_base, int rows, int C, float *s_tile, F f) {
+    const int tid = threadIdx.x;
+    const long long f0 = row_base * C;
+    const int shift = (int)(f0 & 3);
+    const float *src = in + (f0 - shift);
+    const int nfl = rows * C + shift;
+    const int nvec = (nfl + 3) >> 2;
+    for (int v = tid; v < nvec; v += SCAN_BLOCK) {
+        float4 x;
+        if (4 * v + 4 <= nfl) {
+            x = reinterpret_cast<const float4 *>(src)[v];
+        } else {                                   // last vector: never read past the tile
+            x.x = src[4 * v];
+            x.y = (4 * v + 1 < nfl) ? src[4 * v + 1] : 0.f;
+            x.z = (4 * v + 2 < nfl) ? src[4 * v + 2] : 0.f;
+            x.w = 0.f;
+        }
+        reinterpret_cast<float4 *>(s_tile)[v] = x;
+    }
+    __syncthreads();
+    const int r = tid >> 2, sub = tid & 3;
+    if (r < rows) {
+        float *row = s_tile + shift + r * C;
+        if (ACT == ACT_SOFTMAX || ACT == ACT_SOFTMAX_SIGMOID) {
+            float m = -__builtin_inff();
+            for (int c = sub; c < C; c += 4) m = fmaxf(m, row[c]);
+            m = quad_max(m);
+            float sum = 0.f;
+            for (int c = sub; c < C; c += 4) {
+                const float e = __expf(row[c] - m);
+                row[c] = e;
+                sum += e;
+            }
+            sum = quad_sum(sum);
+            const float inv = 1.0f / sum;
+            if (ACT == ACT_SOFTMAX_SIGMOID) {
+                const float sg = sigmoidf_(extra[row_base + r]);
+                for (int c = sub; c < C; c += 4) f((row[c] * inv) * sg, c, r);
+            } else {
+                for (int c = sub; c < C; c += 4) f(row[c] * inv, c, r);
+            }
+        } else if (ACT == ACT_SIGMOID_SIGMOID) {
+            const float so = sigmoidf_(extra[row_base + r]);
+            for (int c = sub; c < C; c += 4) f(sigmoidf_(row[c]) * so, c, r);
+        } else {
+            for (int c = sub; c < C; c += 4) f(row[c], c, r);
+        }
+    }
+    __syncthreads();
+}
+
+template <int ACT>
+__global__ __launch_bounds__(SCAN_BLOCK) void activate_scores_kernel(const float *__restrict__ in,
+                                                                     const float *__restrict__ extra, SelParams sp,
+                                                                     const uint32_t *__restrict__ flag,
+                                                                     float *__restrict__ out) {
+    extern __shared__ float s_dynf[];
+    if (flag && *flag == 0u) return;
+    const int b = blockIdx.y;
+    const int sub0 = blockIdx.x * sp.subs_per_block;
+    const int sub1 = min(sp.n_sub, sub0 + sp.subs_per_block);
+    for (int s = sub0; s < sub1; ++s) {
+        const int r0 = s * SUB_ROWS;
+        const int rows = min(SUB_ROWS, sp.P - r0);
+        const long long row_base = (long long)b * sp.P + r0;
+        float *o = out + row_base * sp.C;
+        const int C = sp.C;
+        activate_subtile<ACT>(in, extra, row_base, rows, C, s_dynf, [&](float sc, int c, int r) { o[r * C + c] = sc; });
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast path
+// ---------------------------------------------------------------------------------------------
+
+template <int ACT>
+__global__ __launch_bounds__(SCAN_BLOCK) void select_sample_kernel(const float *__restrict__ in,
+                                                                   const float *__restrict__ extra, SelParams sp,
+                                                                   uint32_t *__restrict__ shist) {
+    extern __shared__ float s_dynf[];
+    float *s_tile = s_dynf;
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_dynf + sp.tile_floats);   // [Cs][NB/2] packed 16-bit
+    const int b = blockIdx.y;
+    const int words = sp.Cs * (NB / 2);
+    for (int i = threadIdx.x; i < words; i += SCAN_BLOCK) s_hist[i] = 0u;
+    __syncthreads();
+    const float thr = sp.thr;
+    const uint32_t key_thr = sp.key_thr;
+    const int shift = sp.shift, cb = sp.cb;
+    for (int i = 0; i < SAMPLE_SUBS; ++i) {
+        const long long s = (long long)(blockIdx.x * SAMPLE_SUBS + i) * sp.sample_rate;
+        if (s >= sp.n_sub) break;
+        const int r0 = (int)s * SUB_ROWS;
+        const int rows = min(SUB_ROWS, sp.P - r0);
+        activate_subtile<ACT>(in, extra, (long long)b * sp.P + r0, rows, sp.C, s_tile, [&](float sc, int c, int) {
+            if (c >= cb && sc > thr) {
+                const uint32_t bin = bin_of(okey(sc) - key_thr, shift);
+                atomicAdd(&s_hist[(c - cb) * (NB / 2) + (bin >> 1)], 1u << ((bin & 1u) * 16u));
+            }
+        });
+    }
+    uint32_t *gh = shist + (size_t)b * sp.Cs * NB;
+    for (int i = threadIdx.x; i < words; i += SCAN_BLOCK) {
+        const uint32_t v = s_hist[i];
+        if (v) {
+            const uint32_t lo = v & 0xffffu, hi = v >> 16;
+            if (lo) atomicAdd(&gh[2 * i], lo);
+            if (hi) atomicAdd(&gh[2 * i + 1], hi);
+        }
+    }
+}
+
+// Suffix sums of a 256-bin histogram row held four bins per lane; returns the lane's suffix sum.
+__device__ inline uint32_t suffix_scan64(uint32_t t, int lane) {
+    uint32_t suf = t;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_down(suf, o);
+        if (lane + o < 64) suf += up;
+    }
+    return suf;
+}
+
+// Finds the highest bin beta with count(bins >= beta) >= k.  Needs total >= k.  All lanes return the same.
+__device__ inline void find_kth_bin(uint4 q, uint32_t suf, uint32_t t, int lane, uint32_t k, uint32_t &beta,
+                                    uint32_t &n_above, uint32_t &n_beta) {
+    const unsigned long long ge = __ballot(suf >= k);
+    const int L = 63 - __clzll((long long)ge);
+    uint32_t b_ = 0, a_ = 0, nb_ = 0;
+    if (lane == L) {
+        uint32_t acc = suf - t;
+        const uint32_t hb[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {
+            if (acc + hb[i] >= k) { b_ = 4 * L + i; a_ = acc; nb_ = hb[i]; break; }
+            acc += hb[i];
+        }
+    }
+    beta = __shfl(b_, L); n_above = __shfl(a_, L); n_beta = __shfl(nb_, L);
+}
+
+__global__ __launch_bounds__(256) void select_plan_kernel(const uint32_t *__restrict__ shist, SelParams sp,
+                                                          SelRule *__restrict__ rules, uint32_t *__restrict__ flag) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int ci = wave; ci < sp.Cs; ci += nwaves) {
+        SelRule r;
+        r.pad = 0; r.cutoff = 0ull; r.n_above = 0; r.n_sel = 0;
+        if (!sp.use_sample) {
+            r.mode = RULE_PENDING; r.beta = 0; r.min_score = __builtin_inff();
+        } else {
+            const uint32_t *h = shist + ((size_t)b * sp.Cs + ci) * NB;
+            const uint4 q = reinterpret_cast<const uint4 *>(h)[lane];
+            const uint32_t t = q.x + q.y + q.z + q.w;
+            const uint32_t suf = suffix_scan64(t, lane);
+            const uint32_t total = __shfl(suf, 0);
+            r.mode = RULE_STAGED;
+            unsigned long long dmin = 1ull;
+            if (total > (uint32_t)sp.sample_m) {
+                uint32_t beta, n_above, n_beta;
+                find_kth_bin(q, suf, t, lane, (uint32_t)sp.sample_m, beta, n_above, n_beta);
+                dmin = (unsigned long long)beta << sp.shift;
+                if (dmin < 1ull) dmin = 1ull;
+            }
+            r.beta = dmin == 1ull ? 1u : 0u;            // 1: everything above the threshold gets staged
+            r.min_score = score_from_d(sp.key_thr, dmin);
+        }
+        if (lane == 0) rules[(size_t)b * sp.Cs + ci] = r;
+    }
+    if (!sp.use_sample && b == 0 && threadIdx.x == 0) *flag = 1u;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__restrict__ in,
+                                                                 const float *__restrict__ extra, SelParams sp,
+                                                                 const SelRule *__restrict__ rules,
+                                                                 uint32_t *__restrict__ gcnt,
+                                                                 unsigned long long *__restrict__ staging) {
+    extern __shared__ float s_dynf[];
+    float *s_tile = s_dynf;
+    unsigned long long *s_lk = reinterpret_cast<unsigned long long *>(s_dynf + sp.tile_floats);   // [LCAP]
+    uint32_t *s_lmeta = reinterpret_cast<uint32_t *>(s_lk + LCAP);                                // [LCAP]
+    float *s_tlo = reinterpret_cast<float *>(s_lmeta + LCAP);                                     // [MAX_SEL_CLASSES]
+    uint32_t *s_ccount = reinterpret_cast<uint32_t *>(s_tlo + MAX_SEL_CLASSES);
+    uint32_t *s_cbase = s_ccount + MAX_SEL_CLASSES;
+    uint32_t *s_n = s_cbase + MAX_SEL_CLASSES;
+
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int Cs = sp.Cs, cb = sp.cb, cap = sp.cap;
+    const uint32_t key_thr = sp.key_thr;
+    const SelRule *rb = rules + (size_t)b * Cs;
+    uint32_t *gc = gcnt + (size_t)b * Cs;
+    unsigned long long *stg = staging + (size_t)b * Cs * cap;
+    if (tid < Cs) s_tlo[tid] = rb[tid].mode == RULE_STAGED ? rb[tid].min_score : __builtin_inff();
+    if (tid == 0) *s_n = 0u;
+    __syncthreads();
+
+    const int sub0 = blockIdx.x * sp.subs_per_block;
+    const int sub1 = min(sp.n_sub, sub0 + sp.subs_per_block);
+    for (int s = sub0; s < sub1; ++s) {
+        const int r0 = s * SUB_ROWS;
+        const int rows = min(SUB_ROWS, sp.P - r0);
+        activate_subtile<ACT>(in, extra, (long long)b * sp.P + r0, rows, sp.C, s_tile, [&](float sc, int c, int r) {
+            if (c >= cb && sc >= s_tlo[c - cb]) {
+                const int ci = c - cb;
+                const unsigned long long K = make_key(sc, key_thr, (uint32_t)(r0 + r));
+                const uint32_t slot = atomicAdd(s_n, 1u);
+                if (slot < (uint32_t)LCAP) {
+                    s_lk[slot] = K;
+                    s_lmeta[slot] = (uint32_t)ci;
+                } else {                                  // block list full: straight to the staging list
+                    const uint32_t g = atomicAdd(&gc[ci], 1u);
+                    if (g < (uint32_t)cap) stg[(size_t)ci * cap + g] = K;
+                }
+            }
+        });
+        const uint32_t n_raw = *s_n;                      // uniform: activate_subtile ended with a barrier
+        if (n_raw > (uint32_t)(LCAP / 2) || s == sub1 - 1) {
+            const int n = (int)min(n_raw, (uint32_t)LCAP);
+            if (tid < MAX_SEL_CLASSES) s_ccount[tid] = 0u;
+            __syncthreads();
+            for (int e = tid; e < n; e += SCAN_BLOCK) {
+                const uint32_t ci = s_lmeta[e];
+                s_lmeta[e] = ci | (atomicAdd(&s_ccount[ci], 1u) << 16);
+            }
+            __syncthreads();
+            if (tid < Cs && s_ccount[tid]) s_cbase[tid] = atomicAdd(&gc[tid], s_ccount[tid]);
+            __syncthreads();
+            for (int e = tid; e < n; e += SCAN_BLOCK) {
+                const uint32_t meta = s_lmeta[e];
+                const uint32_t ci = meta & 0xffffu;
+                const uint32_t pos = s_cbase[ci] + (meta >> 16);
+                if (pos < (uint32_t)cap) stg[(size_t)ci * cap + pos] = s_lk[e];
+            }
+            __syncthreads();
+            if (tid == 0) *s_n = 0u;
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(128) void select_check_kernel(SelParams sp, SelRule *__restrict__ rules,
+                                                           uint32_t *__restrict__ gcnt, uint32_t *__restrict__ flag) {
+    const int b = blockIdx.x, ci = threadIdx.x;
+    if (ci >= sp.Cs) return;
+    SelRule *r = rules + (size_t)b * sp.Cs + ci;
+    if (r->mode != RULE_STAGED) return;
+    const uint32_t n = gcnt[(size_t)b * sp.Cs + ci];
+    const bool ok = n <= (uint32_t)sp.cap && (r->beta != 0u || n >= (uint32_t)sp.top_k);
+    if (ok) {
+        r->n_sel = n < (uint32_t)sp.top_k ? n : (uint32_t)sp.top_k;
+    } else {
+        r->mode = RULE_PENDING;
+        gcnt[(size_t)b * sp.Cs + ci] = 0u;
+        atomicOr(flag, 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact two-pass fallback (works on activated scores)
+// ---------------------------------------------------------------------------------------------
 
 // Walks the [p0,p1) x C slab of image b with coalesced 16-byte loads; calls f(score, class, element).
 template <typename F>
@@ -84,20 +390,26 @@ __device__ inline void walk_tile(const float *__restrict__ base, int n, int C, F
 }
 
 __global__ __launch_bounds__(PASS_BLOCK) void score_hist_kernel(const float *__restrict__ scores, SelParams sp,
+                                                                const SelRule *__restrict__ rules,
+                                                                const uint32_t *__restrict__ flag,
                                                                 uint32_t *__restrict__ ghist) {
-    extern __shared__ uint32_t s_hist[];   // [Cs][NB/2], two 16-bit counters per word
+    extern __shared__ uint32_t s_hist[];   // [Cs][NB/2] packed 16-bit counters, then [Cs] pending flags
+    if (*flag == 0u) return;
     const int b = blockIdx.y;
     const int p0 = blockIdx.x * sp.tile_anchors;
     const int p1 = min(sp.P, p0 + sp.tile_anchors);
     const int words = sp.Cs * (NB / 2);
+    uint32_t *s_pending = s_hist + words;
     for (int i = threadIdx.x; i < words; i += blockDim.x) s_hist[i] = 0u;
+    for (int i = threadIdx.x; i < sp.Cs; i += blockDim.x)
+        s_pending[i] = rules[(size_t)b * sp.Cs + i].mode == RULE_PENDING ? 1u : 0u;
     __syncthreads();
     const float *base = scores + ((size_t)b * sp.P + p0) * sp.C;
     const float thr = sp.thr;
     const uint32_t key_thr = sp.key_thr;
     const int shift = sp.shift, cb = sp.cb;
     walk_tile(base, (p1 - p0) * sp.C, sp.C, [&](float s, int c, int) {
-        if (c >= cb && s > thr) {
+        if (c >= cb && s > thr && s_pending[c - cb]) {
             const uint32_t bin = bin_of(okey(s) - key_thr, shift);
             atomicAdd(&s_hist[(c - cb) * (NB / 2) + (bin >> 1)], 1u << ((bin & 1u) * 16u));
         }
@@ -114,12 +426,8 @@ __global__ __launch_bounds__(PASS_BLOCK) void score_hist_kernel(const float *__r
     }
 }
 
-__device__ inline float score_from_d(uint32_t key_thr, unsigned long long d) {
-    unsigned long long k = (unsigned long long)key_thr + d;
-    if (k > 0xffffffffull) k = 0xffffffffull;
-    return __uint_as_float(bits_from_okey((uint32_t)k));
-}
-
+// Always runs: turns every PENDING rule into ALL / HIST / EXACT from the full histogram, then lays
+// out the class segments of the output.
 __global__ __launch_bounds__(256) void select_kth_kernel(const uint32_t *__restrict__ ghist, SelParams sp,
                                                          SelRule *__restrict__ rules, int32_t *__restrict__ seg_off,
                                                          int32_t *__restrict__ counts) {
@@ -128,15 +436,15 @@ __global__ __launch_bounds__(256) void select_kth_kernel(const uint32_t *__restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const uint32_t k = (uint32_t)sp.top_k;
     for (int ci = wave; ci < sp.Cs; ci += nwaves) {
+        SelRule *rp = rules + (size_t)b * sp.Cs + ci;
+        if (rp->mode != RULE_PENDING) {
+            if (lane == 0) s_nsel[ci] = (int)rp->n_sel;
+            continue;
+        }
         const uint32_t *h = ghist + ((size_t)b * sp.Cs + ci) * NB;
         const uint4 q = reinterpret_cast<const uint4 *>(h)[lane];       // bins 4*lane .. 4*lane+3
         const uint32_t t = q.x + q.y + q.z + q.w;
-        uint32_t suf = t;                                               // sum over lanes >= lane
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = __shfl_down(suf, o);
-            if (lane + o < 64) suf += up;
-        }
+        const uint32_t suf = suffix_scan64(t, lane);
         const uint32_t total = __shfl(suf, 0);
         SelRule r;
         r.pad = 0; r.cutoff = 0ull; r.beta = 0; r.n_above = 0;
@@ -144,26 +452,15 @@ __global__ __launch_bounds__(256) void select_kth_kernel(const uint32_t *__restr
             r.mode = RULE_ALL; r.n_sel = total;
             r.min_score = score_from_d(sp.key_thr, 1ull);
         } else {
-            const unsigned long long ge = __ballot(suf >= k);           // a prefix of lanes
-            const int L = 63 - __clzll((long long)ge);
-            uint32_t beta = 0, n_above = 0, n_beta = 0;
-            if (lane == L) {
-                uint32_t acc = suf - t;
-                const uint32_t hb[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-                for (int i = 3; i >= 0; --i) {
-                    if (acc + hb[i] >= k) { beta = 4 * L + i; n_above = acc; n_beta = hb[i]; break; }
-                    acc += hb[i];
-                }
-            }
-            beta = __shfl(beta, L); n_above = __shfl(n_above, L); n_beta = __shfl(n_beta, L);
+            uint32_t beta, n_above, n_beta;
+            find_kth_bin(q, suf, t, lane, k, beta, n_above, n_beta);
             r.beta = beta; r.n_above = n_above; r.n_sel = k;
             r.mode = (n_above + n_beta <= (uint32_t)sp.cap) ? RULE_HIST : RULE_EXACT;
             unsigned long long dmin = (unsigned long long)beta << sp.shift;
             if (dmin < 1ull) dmin = 1ull;
             r.min_score = score_from_d(sp.key_thr, dmin);
         }
-        if (lane == 0) { rules[(size_t)b * sp.Cs + ci] = r; s_nsel[ci] = (int)r.n_sel; }
+        if (lane == 0) { *rp = r; s_nsel[ci] = (int)r.n_sel; }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -176,12 +473,14 @@ __global__ __launch_bounds__(256) void select_kth_kernel(const uint32_t *__restr
 }
 
 // Exact cut-off key for (image,class) pairs whose boundary bin holds more scores than the staging
-// list can take.  One block per pair walks its (strided) score column once per 8 key bits.
+// list can take (massive ties).  One block per pair walks its (strided) score column once per 8 key bits.
 __global__ __launch_bounds__(256) void select_refine_kernel(const float *__restrict__ scores, SelParams sp,
-                                                            SelRule *__restrict__ rules) {
+                                                            SelRule *__restrict__ rules,
+                                                            const uint32_t *__restrict__ flag) {
     __shared__ uint32_t s_h[256];
     __shared__ unsigned long long s_lo, s_hi;
     __shared__ uint32_t s_need;
+    if (*flag == 0u) return;
     const int ci = blockIdx.x, b = blockIdx.y;
     SelRule *rp = rules + (size_t)b * sp.Cs + ci;
     if (rp->mode != RULE_EXACT) return;
@@ -205,8 +504,7 @@ __global__ __launch_bounds__(256) void select_refine_kernel(const float *__restr
         for (int p = threadIdx.x; p < sp.P; p += blockDim.x) {
             const float s = col[(size_t)p * sp.C];
             if (s > sp.thr) {
-                const unsigned long long K =
-                    ((unsigned long long)(okey(s) - sp.key_thr) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)p);
+                const unsigned long long K = make_key(s, sp.key_thr, (uint32_t)p);
                 if (K >= lo && K <= hi) atomicAdd(&s_h[(uint32_t)((K - lo) >> sh)], 1u);
             }
         }
@@ -233,15 +531,17 @@ __global__ __launch_bounds__(256) void select_refine_kernel(const float *__restr
 
 __global__ __launch_bounds__(PASS_BLOCK) void select_emit_kernel(const float *__restrict__ scores, SelParams sp,
                                                                  const SelRule *__restrict__ rules,
+                                                                 const uint32_t *__restrict__ flag,
                                                                  uint32_t *__restrict__ cnt,
                                                                  unsigned long long *__restrict__ staging) {
     __shared__ float s_min[MAX_SEL_CLASSES];
+    if (*flag == 0u) return;
     const int b = blockIdx.y;
     const int p0 = blockIdx.x * sp.tile_anchors;
     const int p1 = min(sp.P, p0 + sp.tile_anchors);
     const SelRule *rb = rules + (size_t)b * sp.Cs;
     for (int i = threadIdx.x; i < sp.Cs; i += blockDim.x)
-        s_min[i] = rb[i].n_sel ? rb[i].min_score : __builtin_inff();
+        s_min[i] = (rb[i].mode != RULE_STAGED && rb[i].n_sel) ? rb[i].min_score : __builtin_inff();
     __syncthreads();
     const float *base = scores + ((size_t)b * sp.P + p0) * sp.C;
     const int cb = sp.cb, C = sp.C, shift = sp.shift, cap = sp.cap;
@@ -249,12 +549,11 @@ __global__ __launch_bounds__(PASS_BLOCK) void select_emit_kernel(const float *__
     walk_tile(base, (p1 - p0) * C, C, [&](float s, int c, int e) {
         if (c >= cb && s >= s_min[c - cb]) {
             const int ci = c - cb;
-            const uint32_t d = okey(s) - key_thr;
             const uint32_t p = (uint32_t)(p0 + e / C);
-            const unsigned long long K = ((unsigned long long)d << 32) | (unsigned long long)(0xffffffffu - p);
+            const unsigned long long K = make_key(s, key_thr, p);
             const SelRule r = rb[ci];
             bool take = true;
-            if (r.mode == RULE_HIST) take = bin_of(d, shift) >= r.beta;
+            if (r.mode == RULE_HIST) take = bin_of((uint32_t)(K >> 32), shift) >= r.beta;
             else if (r.mode == RULE_EXACT) take = K >= r.cutoff;
             if (take) {
                 const uint32_t slot = atomicAdd(&cnt[(size_t)b * sp.Cs + ci], 1u);
@@ -263,6 +562,10 @@ __global__ __launch_bounds__(PASS_BLOCK) void select_emit_kernel(const float *__
         }
     });
 }
+
+// ---------------------------------------------------------------------------------------------
+// Finalize: exact top-k of the staged keys, anchor order, decode
+// ---------------------------------------------------------------------------------------------
 
 __device__ inline void bitonic_desc(unsigned long long *s, int n) {
     for (int k = 2; k <= n; k <<= 1) {
@@ -308,82 +611,297 @@ __device__ inline float4 decode_box(const float *__restrict__ anchors, float4 l,
     }
 }
 
+// The n_sel-th largest of the n distinct keys in s_k, by most-significant-digit radix search.
+__device__ inline unsigned long long radix_kth_largest(const unsigned long long *s_k, int n, uint32_t n_sel,
+                                                       uint32_t *s_h, unsigned long long *s_pref, uint32_t *s_rem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) { *s_pref = 0ull; *s_rem = n_sel; }
+    __syncthreads();
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        const unsigned long long pref = *s_pref;
+        s_h[tid] = 0u;                                // blockDim == 256 bins
+        __syncthreads();
+        for (int i = tid; i < n; i += blockDim.x) {
+            const unsigned long long K = s_k[i];
+            if (shift == 56 || (K >> (shift + 8)) == (pref >> (shift + 8)))
+                atomicAdd(&s_h[(uint32_t)(K >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const uint4 q = reinterpret_cast<const uint4 *>(s_h)[lane];
+            const uint32_t t = q.x + q.y + q.z + q.w;
+            const uint32_t suf = suffix_scan64(t, lane);
+            uint32_t digit, above, nd;
+            find_kth_bin(q, suf, t, lane, *s_rem, digit, above, nd);
+            if (lane == 0) { *s_pref = pref | ((unsigned long long)digit << shift); *s_rem -= above; }
+        }
+        __syncthreads();
+    }
+    return *s_pref;
+}
+
 template <int DECODE>
 __global__ __launch_bounds__(256) void select_finalize_kernel(
     SelParams sp, const SelRule *__restrict__ rules, const uint32_t *__restrict__ cnt,
     const unsigned long long *__restrict__ staging, const int32_t *__restrict__ seg_off,
-    const float4 *__restrict__ locs, const float *__restrict__ anchors, int class_id_offset,
+    const float4 *__restrict__ locs, const float *__restrict__ anchors, int class_id_offset, int use_bitmap,
     float4 *__restrict__ out_boxes, float *__restrict__ out_scores, int64_t *__restrict__ out_cls) {
-    extern __shared__ unsigned long long s_k[];
-    const int ci = blockIdx.x, b = blockIdx.y;
+    extern __shared__ unsigned long long s_dyn64[];
+    __shared__ uint32_t s_h[256];
+    __shared__ unsigned long long s_pref;
+    __shared__ uint32_t s_rem;
+    __shared__ uint32_t s_wsum[4];
+    const int ci = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const size_t bc = (size_t)b * sp.Cs + ci;
     const int n_sel = (int)rules[bc].n_sel;
     if (n_sel == 0) return;
     int n_stage = (int)cnt[bc];
     if (n_stage > sp.cap) n_stage = sp.cap;
-    const int n2 = pow2_at_least(n_stage);
-    const unsigned long long *st = staging + bc * sp.cap;
-    for (int i = threadIdx.x; i < n2; i += blockDim.x) s_k[i] = i < n_stage ? st[i] : 0ull;
-    __syncthreads();
-    bitonic_desc(s_k, n2);                      // best (score desc, anchor asc) first
     const int take = min(n_sel, n_stage);
-    const int m2 = pow2_at_least(take);
-    // swap the key halves so that the same descending sort orders by ascending anchor index
-    for (int i = threadIdx.x; i < m2; i += blockDim.x) {
-        unsigned long long v = 0ull;
-        if (i < take) { const unsigned long long K = s_k[i]; v = (K << 32) | (K >> 32); }
-        s_k[i] = v;
-    }
-    __syncthreads();
-    bitonic_desc(s_k, m2);
+    const unsigned long long *st = staging + bc * sp.cap;
     const size_t row0 = (size_t)b * ((size_t)sp.Cs * sp.top_k) + (size_t)seg_off[(size_t)b * (sp.Cs + 1) + ci];
-    for (int i = threadIdx.x; i < take; i += blockDim.x) {
-        const unsigned long long K2 = s_k[i];
-        const uint32_t p = 0xffffffffu - (uint32_t)(K2 >> 32);
-        const uint32_t d = (uint32_t)K2;
+    unsigned long long *s_k = s_dyn64;                                  // [cap]
+
+    auto emit = [&](int rank, unsigned long long K) {
+        const uint32_t p = 0xffffffffu - (uint32_t)(K & 0xffffffffull);
+        const uint32_t d = (uint32_t)(K >> 32);
         const float4 l = locs[(size_t)b * sp.P + p];
-        out_boxes[row0 + i] = decode_box<DECODE>(anchors, l, p);
-        out_scores[row0 + i] = __uint_as_float(bits_from_okey(sp.key_thr + d));
-        out_cls[row0 + i] = (int64_t)(ci + sp.cb + class_id_offset);
+        out_boxes[row0 + rank] = decode_box<DECODE>(anchors, l, p);
+        out_scores[row0 + rank] = __uint_as_float(bits_from_okey(sp.key_thr + d));
+        out_cls[row0 + rank] = (int64_t)(ci + sp.cb + class_id_offset);
+    };
+
+    if (use_bitmap) {
+        for (int i = tid; i < n_stage; i += blockDim.x) s_k[i] = st[i];
+        __syncthreads();
+        unsigned long long cutoff = 0ull;
+        if (n_stage > take) cutoff = radix_kth_largest(s_k, n_stage, (uint32_t)take, s_h, &s_pref, &s_rem);
+        // anchor order through a P-bit bitmap: rank = number of selected anchors below mine
+        const int words = (sp.P + 63) >> 6;
+        unsigned long long *s_bm = s_k + sp.cap;                        // [words]
+        uint32_t *s_wp = reinterpret_cast<uint32_t *>(s_bm + words);    // [words] exclusive popcount prefix
+        for (int w = tid; w < words; w += blockDim.x) s_bm[w] = 0ull;
+        __syncthreads();
+        for (int i = tid; i < n_stage; i += blockDim.x) {
+            const unsigned long long K = s_k[i];
+            if (K >= cutoff) {
+                const uint32_t p = 0xffffffffu - (uint32_t)(K & 0xffffffffull);
+                atomicOr(&s_bm[p >> 6], 1ull << (p & 63u));
+            }
+        }
+        __syncthreads();
+        // block-wide exclusive scan of per-word popcounts: each thread owns a contiguous run of words
+        const int wpt = (words + 255) >> 8;
+        const int w0 = tid * wpt, w1 = min(words, w0 + wpt);
+        uint32_t local = 0;
+        for (int w = w0; w < w1; ++w) local += (uint32_t)__popcll(s_bm[w]);
+        uint32_t inc = local;
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(inc, o);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        uint32_t base = inc - local;
+        for (int w = 0; w < wave; ++w) base += s_wsum[w];
+        for (int w = w0; w < w1; ++w) { s_wp[w] = base; base += (uint32_t)__popcll(s_bm[w]); }
+        __syncthreads();
+        for (int i = tid; i < n_stage; i += blockDim.x) {
+            const unsigned long long K = s_k[i];
+            if (K >= cutoff) {
+                const uint32_t p = 0xffffffffu - (uint32_t)(K & 0xffffffffull);
+                const uint32_t rank = s_wp[p >> 6] + (uint32_t)__popcll(s_bm[p >> 6] & ((1ull << (p & 63u)) - 1ull));
+                emit((int)rank, K);
+            }
+        }
+    } else {
+        // very large P: sort the staged keys, cut, then sort the survivors by anchor index
+        const int n2 = pow2_at_least(n_stage);
+        for (int i = tid; i < n2; i += blockDim.x) s_k[i] = i < n_stage ? st[i] : 0ull;
+        __syncthreads();
+        bitonic_desc(s_k, n2);
+        const int m2 = pow2_at_least(take);
+        for (int i = tid; i < m2; i += blockDim.x) {
+            unsigned long long v = 0ull;
+            if (i < take) { const unsigned long long K = s_k[i]; v = (K << 32) | (K >> 32); }
+            s_k[i] = v;
+        }
+        __syncthreads();
+        bitonic_desc(s_k, m2);
+        for (int i = tid; i < take; i += blockDim.x) {
+            const unsigned long long K2 = s_k[i];
+            emit(i, (K2 << 32) | (K2 >> 32));
+        }
     }
 }
 
-int staging_cap(int top_k) {
-    int slack = top_k / 2 > 256 ? top_k / 2 : 256;
-    int need = top_k + slack, cap = 2;
+// ---------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------
+
+int pow2_ge(long long need) {
+    int cap = 2;
     while (cap < need) cap <<= 1;
     return cap;
 }
 
-struct SelLayout { size_t hist, cnt, rules, staging, total, zero_bytes; };
+struct SamplePlan { int use_sample, rate, m, cap; };
 
-SelLayout layout(int64_t B, int64_t Cs, int cap) {
+// Sampling plan.  With a 1-in-rate sample, the score whose sample rank is m has, with probability
+// about 1 - 3e-6 (z = 4.5 standard deviations of the binomial), at least top_k scores at or above it.
+SamplePlan make_plan(int64_t P, int top_k) {
+    SamplePlan sp;
+    const double z = 4.5;
+    if (P < 4096) {
+        int slack = top_k / 2 > 256 ? top_k / 2 : 256;
+        sp.use_sample = 0; sp.rate = 1; sp.m = 0; sp.cap = pow2_ge(top_k + slack);
+        return sp;
+    }
+    int rate = P >= 65536 ? 16 : (P >= 16384 ? 8 : 4);
+    for (;;) {
+        const double kr = (double)top_k / rate;
+        const double sq = 0.5 * (z + std::sqrt(z * z + 4.0 * kr));
+        const int m = (int)std::ceil(sq * sq);
+        const double upper = (double)m * rate + z * rate * std::sqrt((double)m);
+        const int cap = pow2_ge((long long)(1.25 * upper) + 64);
+        if (cap <= 8192 || rate <= 2) {
+            sp.use_sample = 1; sp.rate = rate; sp.m = m; sp.cap = cap < 8192 ? cap : 8192;
+            return sp;
+        }
+        rate /= 2;
+    }
+}
+
+struct SelLayout { size_t hist, shist, cnt, flag, rules, staging, scores, total, zero_bytes; };
+
+SelLayout layout(int64_t B, int64_t P, int64_t C, int64_t Cs, int cap, int act) {
     SelLayout L;
     size_t off = 0;
     L.hist = off; off = align_up(off + (size_t)B * Cs * NB * sizeof(uint32_t), 256);
+    L.shist = off; off = align_up(off + (size_t)B * Cs * NB * sizeof(uint32_t), 256);
     L.cnt = off; off = align_up(off + (size_t)B * Cs * sizeof(uint32_t), 256);
-    L.zero_bytes = off;                      // histogram + counters are cleared every call
+    L.flag = off; off = align_up(off + sizeof(uint32_t), 256);
+    L.zero_bytes = off;                      // histograms, counters and the flag are cleared every call
     L.rules = off; off = align_up(off + (size_t)B * Cs * sizeof(SelRule), 256);
     L.staging = off; off = align_up(off + (size_t)B * Cs * cap * sizeof(unsigned long long), 256);
+    L.scores = off;
+    if (act != ACT_NONE) off = align_up(off + (size_t)B * P * C * sizeof(float), 256);   // fallback only
     L.total = off;
     return L;
 }
 
-}  // namespace
+int tile_floats_for(int64_t C) { return (int)(((SUB_ROWS * C + 6) / 4 + 1) * 4); }
 
-extern "C" size_t detbox_select_decode_workspace_bytes(int64_t B, int64_t P, int64_t C, int class_begin, int top_k) {
-    (void)P;
-    if (B <= 0 || C <= class_begin || top_k <= 0) return 256;
-    return layout(B, C - class_begin, staging_cap(top_k)).total;
+template <typename K>
+int set_lds(K kernel, size_t lds) {
+    if (lds > 64 * 1024)
+        DETBOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return DETBOX_OK;
 }
 
-extern "C" int detbox_select_decode(int decode_mode, const float *scores, const float *locs, const float *anchors,
+template <int ACT>
+int launch_fast(const float *in, const float *extra, const SelParams &sp, int64_t B, uint32_t *shist, SelRule *rules,
+                uint32_t *flag, uint32_t *cnt, unsigned long long *staging, float *scores_ws, hipStream_t s) {
+    const size_t tile_bytes = (size_t)sp.tile_floats * 4;
+    if (sp.use_sample) {
+        const int64_t n_sampled = (sp.n_sub + sp.sample_rate - 1) / sp.sample_rate;
+        const size_t lds = tile_bytes + (size_t)sp.Cs * (NB / 2) * 4;
+        if (int rc = set_lds(select_sample_kernel<ACT>, lds)) return rc;
+        ProfScope ps("select_sample", s);
+        select_sample_kernel<ACT><<<dim3((unsigned)((n_sampled + SAMPLE_SUBS - 1) / SAMPLE_SUBS), (unsigned)B),
+                                    dim3(SCAN_BLOCK), lds, s>>>(in, extra, sp, shist);
+        DETBOX_LAUNCH_CHECK();
+    }
+    {
+        ProfScope ps("select_plan", s);
+        select_plan_kernel<<<dim3((unsigned)B), dim3(256), 0, s>>>(shist, sp, rules, flag);
+        DETBOX_LAUNCH_CHECK();
+    }
+    const unsigned gx = (unsigned)((sp.n_sub + sp.subs_per_block - 1) / sp.subs_per_block);
+    if (sp.use_sample) {
+        const size_t lds = tile_bytes + (size_t)LCAP * 12 + (size_t)MAX_SEL_CLASSES * 12 + 16;
+        if (int rc = set_lds(select_scan_kernel<ACT>, lds)) return rc;
+        {
+            ProfScope ps("select_scan", s);
+            select_scan_kernel<ACT><<<dim3(gx, (unsigned)B), dim3(SCAN_BLOCK), lds, s>>>(in, extra, sp, rules, cnt, staging);
+            DETBOX_LAUNCH_CHECK();
+        }
+        ProfScope ps("select_check", s);
+        select_check_kernel<<<dim3((unsigned)B), dim3(128), 0, s>>>(sp, rules, cnt, flag);
+        DETBOX_LAUNCH_CHECK();
+    }
+    if (ACT != ACT_NONE) {
+        if (int rc = set_lds(activate_scores_kernel<ACT>, tile_bytes)) return rc;
+        ProfScope ps("select_materialize", s);
+        activate_scores_kernel<ACT><<<dim3(gx, (unsigned)B), dim3(SCAN_BLOCK), tile_bytes, s>>>(in, extra, sp, flag, scores_ws);
+        DETBOX_LAUNCH_CHECK();
+    }
+    return DETBOX_OK;
+}
+
+int check_act(int activation, const float *extra) {
+    DETBOX_CHECK_ARG(activation >= ACT_NONE && activation <= ACT_SIGMOID_SIGMOID, "unknown activation");
+    DETBOX_CHECK_ARG(activation == ACT_NONE || activation == ACT_SOFTMAX || extra, "this activation needs `extra`");
+    return DETBOX_OK;
+}
+
+}  // namespace
+
+extern "C" int detbox_activate_scores(int activation, const float *in, const float *extra, int64_t B, int64_t P,
+                                      int64_t C, float *out, void *stream) {
+    if (int rc = check_act(activation, extra)) return rc;
+    DETBOX_CHECK_ARG(B >= 0 && P >= 0 && C >= 1 && P < (1ll << 31) && B <= 65535, "bad size");
+    if (B == 0 || P == 0) return DETBOX_OK;
+    DETBOX_CHECK_ARG(in && out, "null pointer");
+    DETBOX_CHECK_ARG((uintptr_t)in % 16 == 0, "input must be 16-byte aligned");
+    if (C > 4 * MAX_SEL_CLASSES) {
+        set_error("detbox_activate_scores: C = %lld beyond the limit %d", (long long)C, 4 * MAX_SEL_CLASSES);
+        return DETBOX_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    SelParams sp;
+    std::memset(&sp, 0, sizeof(sp));
+    sp.P = (int)P; sp.C = (int)C;
+    sp.n_sub = (int)((P + SUB_ROWS - 1) / SUB_ROWS);
+    sp.tile_floats = tile_floats_for(C);
+    int64_t spb = (B * sp.n_sub + 4095) / 4096;
+    sp.subs_per_block = (int)(spb < 1 ? 1 : spb);
+    const unsigned gx = (unsigned)((sp.n_sub + sp.subs_per_block - 1) / sp.subs_per_block);
+    const size_t lds = (size_t)sp.tile_floats * 4;
+    ProfScope ps("activate_scores", s);
+    switch (activation) {
+#define DETBOX_ACT_CASE(A)                                                                                      \
+    case A:                                                                                                     \
+        if (int rc = set_lds(activate_scores_kernel<A>, lds)) return rc;                                        \
+        activate_scores_kernel<A><<<dim3(gx, (unsigned)B), dim3(SCAN_BLOCK), lds, s>>>(in, extra, sp, nullptr, out); \
+        break;
+        DETBOX_ACT_CASE(ACT_NONE)
+        DETBOX_ACT_CASE(ACT_SOFTMAX)
+        DETBOX_ACT_CASE(ACT_SOFTMAX_SIGMOID)
+        DETBOX_ACT_CASE(ACT_SIGMOID_SIGMOID)
+#undef DETBOX_ACT_CASE
+    }
+    DETBOX_LAUNCH_CHECK();
+    return DETBOX_OK;
+}
+
+extern "C" size_t detbox_select_decode_workspace_bytes(int64_t B, int64_t P, int64_t C, int class_begin, int top_k,
+                                                       int activation) {
+    if (B <= 0 || C <= class_begin || top_k <= 0) return 256;
+    return layout(B, P, C, C - class_begin, make_plan(P, top_k).cap, activation).total;
+}
+
+extern "C" int detbox_select_decode(int decode_mode, int activation, const float *scores, const float *extra,
+                                    const float *locs, const float *anchors,
                                     int64_t B, int64_t P, int64_t C, int class_begin, int class_id_offset,
                                     float conf_thresh, int top_k, float score_hi_hint,
                                     float *out_boxes, float *out_scores, int64_t *out_class_ids,
                                     int32_t *out_seg_offsets, int32_t *out_counts,
                                     void *workspace, size_t workspace_bytes, void *stream) {
     DETBOX_CHECK_ARG(decode_mode >= 0 && decode_mode <= 2, "unknown decode mode");
+    if (int rc = check_act(activation, extra)) return rc;
     DETBOX_CHECK_ARG(B >= 0 && P >= 0 && C >= 1, "bad size");
     DETBOX_CHECK_ARG(class_begin >= 0 && class_begin < C, "class_begin out of range");
     DETBOX_CHECK_ARG(!(conf_thresh != conf_thresh), "conf_thresh is NaN");
@@ -392,11 +910,13 @@ extern "C" int detbox_select_decode(int decode_mode, const float *scores, const 
         return DETBOX_ERR_UNSUPPORTED;
     }
     const int64_t Cs = C - class_begin;
-    if (Cs > MAX_SEL_CLASSES) {
-        set_error("detbox_select_decode: %lld selected classes, limit %d", (long long)Cs, MAX_SEL_CLASSES);
+    if (Cs > MAX_SEL_CLASSES || C > 2 * MAX_SEL_CLASSES) {
+        set_error("detbox_select_decode: %lld selected classes of %lld, limits %d / %d", (long long)Cs, (long long)C,
+                  MAX_SEL_CLASSES, 2 * MAX_SEL_CLASSES);
         return DETBOX_ERR_UNSUPPORTED;
     }
     DETBOX_CHECK_ARG(P < (1ll << 31) && P * C < (1ll << 40), "P too large");
+    DETBOX_CHECK_ARG(B <= 65535, "B > 65535");
     if (B == 0) return DETBOX_OK;
     DETBOX_CHECK_ARG(out_seg_offsets && out_counts, "null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -406,23 +926,29 @@ extern "C" int detbox_select_decode(int decode_mode, const float *scores, const 
         return DETBOX_OK;
     }
     DETBOX_CHECK_ARG(scores && locs && anchors && out_boxes && out_scores && out_class_ids, "null pointer");
-    DETBOX_CHECK_ARG((uintptr_t)scores % 4 == 0 && (uintptr_t)locs % 16 == 0 && (uintptr_t)out_boxes % 16 == 0,
-                     "misaligned array");
+    DETBOX_CHECK_ARG((uintptr_t)scores % 16 == 0 && (uintptr_t)locs % 16 == 0 && (uintptr_t)out_boxes % 16 == 0,
+                     "scores, locs and out_boxes must be 16-byte aligned");
     DETBOX_CHECK_ARG(decode_mode != DETBOX_DECODE_CXCYWH || (uintptr_t)anchors % 16 == 0, "anchors must be 16-byte aligned");
     DETBOX_CHECK_ARG(decode_mode != DETBOX_DECODE_FCOS || (uintptr_t)anchors % 8 == 0, "points must be 8-byte aligned");
-    const int cap = staging_cap(top_k);
-    const SelLayout L = layout(B, Cs, cap);
+    const SamplePlan plan = make_plan(P, top_k);
+    const int cap = plan.cap;
+    const SelLayout L = layout(B, P, C, Cs, cap, activation);
     if (!workspace || (uintptr_t)workspace % 256 || workspace_bytes < L.total) {
         set_error("detbox_select_decode: workspace missing, misaligned or smaller than %zu bytes", L.total);
         return DETBOX_ERR_WORKSPACE;
     }
     char *ws = static_cast<char *>(workspace);
     uint32_t *ghist = reinterpret_cast<uint32_t *>(ws + L.hist);
+    uint32_t *shist = reinterpret_cast<uint32_t *>(ws + L.shist);
     uint32_t *cnt = reinterpret_cast<uint32_t *>(ws + L.cnt);
+    uint32_t *flag = reinterpret_cast<uint32_t *>(ws + L.flag);
     SelRule *rules = reinterpret_cast<SelRule *>(ws + L.rules);
     unsigned long long *staging = reinterpret_cast<unsigned long long *>(ws + L.staging);
+    float *scores_ws = reinterpret_cast<float *>(ws + L.scores);
+    const float *scores_eff = activation == ACT_NONE ? scores : scores_ws;
 
     SelParams sp;
+    std::memset(&sp, 0, sizeof(sp));
     sp.P = (int)P; sp.C = (int)C; sp.cb = class_begin; sp.Cs = (int)Cs; sp.top_k = top_k; sp.cap = cap;
     sp.thr = conf_thresh;
     uint32_t tb, hb;
@@ -441,13 +967,26 @@ extern "C" int detbox_select_decode(int decode_mode, const float *scores, const 
     if (tile > P) tile = P;
     sp.tile_anchors = (int)tile;
     const int64_t tiles = (P + tile - 1) / tile;
-    DETBOX_CHECK_ARG(B <= 65535, "B > 65535");
+    sp.use_sample = plan.use_sample; sp.sample_rate = plan.rate; sp.sample_m = plan.m;
+    sp.n_sub = (int)((P + SUB_ROWS - 1) / SUB_ROWS);
+    sp.tile_floats = tile_floats_for(C);
+    int64_t spb = (B * sp.n_sub + 4095) / 4096;
+    sp.subs_per_block = (int)(spb < 1 ? 1 : spb);
 
     DETBOX_HIP(hipMemsetAsync(ws, 0, L.zero_bytes, s));
+    int rc = DETBOX_OK;
+    switch (activation) {
+        case ACT_NONE: rc = launch_fast<ACT_NONE>(scores, extra, sp, B, shist, rules, flag, cnt, staging, scores_ws, s); break;
+        case ACT_SOFTMAX: rc = launch_fast<ACT_SOFTMAX>(scores, extra, sp, B, shist, rules, flag, cnt, staging, scores_ws, s); break;
+        case ACT_SOFTMAX_SIGMOID: rc = launch_fast<ACT_SOFTMAX_SIGMOID>(scores, extra, sp, B, shist, rules, flag, cnt, staging, scores_ws, s); break;
+        default: rc = launch_fast<ACT_SIGMOID_SIGMOID>(scores, extra, sp, B, shist, rules, flag, cnt, staging, scores_ws, s); break;
+    }
+    if (rc) return rc;
     {
         ProfScope ps("score_hist", s);
-        score_hist_kernel<<<dim3((unsigned)tiles, (unsigned)B), dim3(PASS_BLOCK), (size_t)Cs * (NB / 2) * 4, s>>>(
-            scores, sp, ghist);
+        const size_t lds = (size_t)Cs * (NB / 2) * 4 + (size_t)Cs * 4;
+        if (int rc2 = set_lds(score_hist_kernel, lds)) return rc2;
+        score_hist_kernel<<<dim3((unsigned)tiles, (unsigned)B), dim3(PASS_BLOCK), lds, s>>>(scores_eff, sp, rules, flag, ghist);
         DETBOX_LAUNCH_CHECK();
     }
     {
@@ -457,29 +996,32 @@ extern "C" int detbox_select_decode(int decode_mode, const float *scores, const 
     }
     {
         ProfScope ps("select_refine", s);
-        select_refine_kernel<<<dim3((unsigned)Cs, (unsigned)B), dim3(256), 0, s>>>(scores, sp, rules);
+        select_refine_kernel<<<dim3((unsigned)Cs, (unsigned)B), dim3(256), 0, s>>>(scores_eff, sp, rules, flag);
         DETBOX_LAUNCH_CHECK();
     }
     {
         ProfScope ps("select_emit", s);
-        select_emit_kernel<<<dim3((unsigned)tiles, (unsigned)B), dim3(PASS_BLOCK), 0, s>>>(scores, sp, rules, cnt, staging);
+        select_emit_kernel<<<dim3((unsigned)tiles, (unsigned)B), dim3(PASS_BLOCK), 0, s>>>(scores_eff, sp, rules, flag, cnt, staging);
         DETBOX_LAUNCH_CHECK();
     }
     {
         ProfScope ps("select_finalize", s);
         dim3 grid((unsigned)Cs, (unsigned)B);
-        const size_t lds = (size_t)cap * sizeof(unsigned long long);
+        const int words = (int)((P + 63) / 64);
+        const int use_bitmap = words <= BITMAP_MAX_WORDS ? 1 : 0;
+        const size_t lds = (size_t)cap * 8 + (use_bitmap ? (size_t)words * 12 + 16 : 0);
         const float4 *l4 = reinterpret_cast<const float4 *>(locs);
         float4 *ob = reinterpret_cast<float4 *>(out_boxes);
-        if (decode_mode == DETBOX_DECODE_CXCYWH)
-            select_finalize_kernel<DETBOX_DECODE_CXCYWH><<<grid, dim3(256), lds, s>>>(
-                sp, rules, cnt, staging, out_seg_offsets, l4, anchors, class_id_offset, ob, out_scores, out_class_ids);
-        else if (decode_mode == DETBOX_DECODE_YOLO)
-            select_finalize_kernel<DETBOX_DECODE_YOLO><<<grid, dim3(256), lds, s>>>(
-                sp, rules, cnt, staging, out_seg_offsets, l4, anchors, class_id_offset, ob, out_scores, out_class_ids);
-        else
-            select_finalize_kernel<DETBOX_DECODE_FCOS><<<grid, dim3(256), lds, s>>>(
-                sp, rules, cnt, staging, out_seg_offsets, l4, anchors, class_id_offset, ob, out_scores, out_class_ids);
+#define DETBOX_FIN_CASE(D)                                                                                       \
+    {                                                                                                            \
+        if (int rc2 = set_lds(select_finalize_kernel<D>, lds)) return rc2;                                       \
+        select_finalize_kernel<D><<<grid, dim3(256), lds, s>>>(sp, rules, cnt, staging, out_seg_offsets, l4, anchors, \
+                                                               class_id_offset, use_bitmap, ob, out_scores, out_class_ids); \
+    }
+        if (decode_mode == DETBOX_DECODE_CXCYWH) DETBOX_FIN_CASE(DETBOX_DECODE_CXCYWH)
+        else if (decode_mode == DETBOX_DECODE_YOLO) DETBOX_FIN_CASE(DETBOX_DECODE_YOLO)
+        else DETBOX_FIN_CASE(DETBOX_DECODE_FCOS)
+#undef DETBOX_FIN_CASE
         DETBOX_LAUNCH_CHECK();
     }
     return DETBOX_OK;

@@ -9,8 +9,9 @@ part of this package: a class here holds only the anchor/point table.
 
 Inside `loss`, Step 1 (target assignment) is one batched HIP call; Steps 2-5 are
 the reference's differentiable loss arithmetic in plain PyTorch.  `pre_predict`
-keeps the activation in PyTorch-ROCm and hands the activated scores to the HIP
-threshold/top-k/decode path.  `detect` chains pre_predict -> NMS -> result rows
+hands the raw head outputs to the HIP path, which fuses the activation (soft-max,
+soft-max x sigmoid(centerness), sigmoid x sigmoid(objectness)) into the
+threshold/top-k/decode pass.  `detect` chains pre_predict -> NMS -> result rows
 without leaving the device.
 """
 from __future__ import annotations
@@ -57,12 +58,20 @@ class _BoxOps:
             self._dev_tables[key] = t.to(device=device, dtype=torch.float32).contiguous()
         return self._dev_tables[key]
 
-    # -- subclasses provide: _anchors_for_decode(), _activate(outputs) -> (locs, scores)
+    activation = ops.ACT_SOFTMAX
+
+    # -- subclasses provide: _anchors_for_decode(), _head(outputs) -> (locs, class head output, extra)
+    def _activate(self, outputs: tuple):
+        """(locs, activated scores [B,P,C]) with the scores exactly as the fused kernels compute them."""
+        locs, head, extra = self._head(outputs)
+        return locs, ops.activate_scores(head.contiguous(), None if extra is None else extra.contiguous(), self.activation)
+
     def candidates(self, outputs: tuple, conf_thresh: float = 0.01, top_k: int = 200) -> ops.Candidates:
-        locs, scores = self._activate(outputs)
-        anchors = self._table(self._anchors_for_decode(), scores.device)
-        return ops.select_decode(scores.contiguous(), locs.contiguous(), anchors, self.decode_mode,
-                                 self.class_begin, self.class_id_offset, conf_thresh, top_k)
+        locs, head, extra = self._head(outputs)
+        anchors = self._table(self._anchors_for_decode(), head.device)
+        return ops.select_decode(head.contiguous(), locs.contiguous(), anchors, self.decode_mode,
+                                 self.class_begin, self.class_id_offset, conf_thresh, top_k,
+                                 activation=self.activation, extra=None if extra is None else extra.contiguous())
 
     def pre_predict(self, outputs: tuple, conf_thresh: float = 0.01, top_k: int = 200) -> tuple:
         c = self.candidates(outputs, conf_thresh, top_k)
@@ -101,9 +110,9 @@ class SSD300(_BoxOps):
     def _anchors_for_decode(self):
         return self.dboxes
 
-    def _activate(self, outputs):
+    def _head(self, outputs):
         out_locs, out_confs = outputs
-        return out_locs.detach(), F.softmax(out_confs, dim=-1).detach()
+        return out_locs.detach(), out_confs.detach(), None
 
     def assign(self, gt_bboxes: list, gt_labels: list, device, iou_thresh: float = 0.5, want_best=False):
         gb, gl, off, total = ops.pack_gt(gt_bboxes, gt_labels, device)
@@ -150,9 +159,9 @@ class RetinaNet(_BoxOps):
     def _anchors_for_decode(self):
         return self.pboxes
 
-    def _activate(self, outputs):
+    def _head(self, outputs):
         out_locs, out_confs = outputs
-        return out_locs.detach(), F.softmax(out_confs, dim=-1).detach()
+        return out_locs.detach(), out_confs.detach(), None
 
     def assign(self, gt_bboxes, gt_labels, device, iou_threshs: tuple = (0.4, 0.5), want_best=False):
         gb, gl, off, total = ops.pack_gt(gt_bboxes, gt_labels, device)
@@ -176,6 +185,7 @@ class FCOS(_BoxOps):
     """Box-ops of src/models/fcos.py (points/ranges :142-173, loss :175-279, pre_predict :299-343).
     image_size is 512 in the reference (hard-coded at :152)."""
     decode_mode = ops.DECODE_FCOS
+    activation = ops.ACT_SOFTMAX_SIGMOID
 
     def __init__(self, num_classes: int, f_k_list: Sequence[int] = (64, 32, 16, 8, 4), image_size: float = 512):
         super().__init__()
@@ -186,9 +196,9 @@ class FCOS(_BoxOps):
     def _anchors_for_decode(self):
         return self.points
 
-    def _activate(self, outputs):
+    def _head(self, outputs):
         out_locs, out_confs, out_cents = outputs
-        return out_locs.detach(), (F.softmax(out_confs, dim=-1) * out_cents.sigmoid()[..., None]).detach()
+        return out_locs.detach(), out_confs.detach(), out_cents.detach()
 
     def assign(self, gt_bboxes, gt_labels, device):
         gb, gl, off, total = ops.pack_gt(gt_bboxes, gt_labels, device)
@@ -217,6 +227,7 @@ class YoloV3(_BoxOps):
     decode_mode = ops.DECODE_YOLO
     class_begin = 0
     class_id_offset = 1      # emitted class id = column + 1 (yolov3.py:319)
+    activation = ops.ACT_SIGMOID_SIGMOID
 
     def __init__(self, num_classes: int):
         super().__init__()
@@ -226,11 +237,11 @@ class YoloV3(_BoxOps):
     def _anchors_for_decode(self):
         return self.pboxes
 
-    def _activate(self, outputs):
+    def _head(self, outputs):
         out_locs, out_objs, out_confs = outputs
         out_locs = out_locs.detach()
-        out_locs[..., :2] = out_locs[..., :2].sigmoid()
-        return out_locs, (out_confs.sigmoid() * out_objs.sigmoid()[..., None]).detach()
+        out_locs[..., :2] = out_locs[..., :2].sigmoid()        # in place, like yolov3.py:297
+        return out_locs, out_confs.detach(), out_objs.detach()
 
     def assign(self, gt_bboxes, gt_labels, device, iou_thresh: float = 0.5, want_best=False):
         gb, gl, off, total = ops.pack_gt(gt_bboxes, gt_labels, device)

@@ -24,6 +24,7 @@ from . import _lib
 FMT = {'xyxy': 0, 'xywh': 1, 'cxcywh': 2}
 ASSIGN_CXCYWH, ASSIGN_YOLO = 0, 1
 DECODE_CXCYWH, DECODE_YOLO, DECODE_FCOS = 0, 1, 2
+ACT_NONE, ACT_SOFTMAX, ACT_SOFTMAX_SIGMOID, ACT_SIGMOID_SIGMOID = 0, 1, 2, 3
 MAX_TOP_K = 4096
 NMS_MAX_SORT = 4096
 
@@ -184,9 +185,23 @@ class Candidates:
     top_k: int
 
 
+def activate_scores(head: torch.Tensor, extra: Optional[torch.Tensor], activation: int) -> torch.Tensor:
+    """The activated scores [B,P,C] exactly as select_decode computes them internally."""
+    dev = head.device
+    B, P, C = head.shape
+    out = torch.empty_like(head)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().detbox_activate_scores(activation, _ptr(head), _ptr(extra), B, P, C, _ptr(out), _stream(dev)),
+                   'detbox_activate_scores')
+    return out
+
+
 def select_decode(scores: torch.Tensor, locs: torch.Tensor, anchors: torch.Tensor, decode_mode: int,
                   class_begin: int, class_id_offset: int, conf_thresh: float, top_k: int,
-                  score_hi_hint: float = 1.0) -> Candidates:
+                  score_hi_hint: float = 1.0, activation: int = ACT_NONE,
+                  extra: Optional[torch.Tensor] = None) -> Candidates:
+    """scores: [B,P,C] activated scores (activation == ACT_NONE) or raw head output to be activated in
+    the kernel; extra: [B,P] centerness / objectness logits for the activations that use them."""
     dev = scores.device
     B, P, C = scores.shape
     S = C - class_begin
@@ -198,9 +213,9 @@ def select_decode(scores: torch.Tensor, locs: torch.Tensor, anchors: torch.Tenso
     counts = torch.empty((B,), dtype=torch.int32, device=dev)
     L = _lib.lib()
     with torch.cuda.device(dev):
-        ws = _workspace(dev, L.detbox_select_decode_workspace_bytes(B, P, C, class_begin, top_k), 'select')
-        _lib.check(L.detbox_select_decode(decode_mode, _ptr(scores), _ptr(locs), _ptr(anchors), B, P, C, class_begin,
-                                          class_id_offset, conf_thresh, top_k, score_hi_hint,
+        ws = _workspace(dev, L.detbox_select_decode_workspace_bytes(B, P, C, class_begin, top_k, activation), 'select')
+        _lib.check(L.detbox_select_decode(decode_mode, activation, _ptr(scores), _ptr(extra), _ptr(locs), _ptr(anchors),
+                                          B, P, C, class_begin, class_id_offset, conf_thresh, top_k, score_hi_hint,
                                           out_boxes.data_ptr(), out_scores.data_ptr(), out_cls.data_ptr(),
                                           seg.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
                    'detbox_select_decode')

@@ -323,14 +323,24 @@ def test_select_ties_and_degenerate_inputs(D, oracle, dev):
     check_select((pb, ps, pc), oracle_select(O, s[:1], locs[:1], anchors, 0, 1, 0, 0.01, 50, fast=False))
 
 
+def torch_activation(m, outputs):
+    """The reference's activation in plain PyTorch (ssd300.py:354, fcos.py:314, yolov3.py:298-300)."""
+    if m.activation == 1:
+        return torch.softmax(outputs[1], -1)
+    if m.activation == 2:
+        return torch.softmax(outputs[1], -1) * outputs[2].sigmoid()[..., None]
+    return outputs[2].sigmoid() * outputs[1].sigmoid()[..., None]
+
+
 def test_models_pre_predict_level2(D, oracle, dev):
-    """pre_predict of the four model classes (activation in PyTorch-ROCm + HIP selection) against
-    the oracle fed with the very scores the GPU activation produced."""
+    """pre_predict of the four model classes (activation fused into the HIP selection) against the
+    oracle fed with the very scores the kernels ranked (detbox_activate_scores, same arithmetic),
+    which in turn must agree with the PyTorch activation to fp32 rounding."""
     O = oracle
     g = torch.Generator().manual_seed(9)
     cases = [
         (D.SSD300(20), 21, None), (D.RetinaNet(20, [32, 16, 8, 4, 2]), 21, None),
-        (D.FCOS(20), 21, 'cent'), (D.YoloV3(20), 20, 'obj'),
+        (D.FCOS(20), 21, 'cent'), (D.YoloV3(20), 20, 'obj'), (D.RetinaNet(4, [8, 4, 2, 1, 1]), 5, None),
     ]
     for m, C, extra in cases:
         P = m._anchors_for_decode().shape[0]
@@ -345,6 +355,8 @@ def test_models_pre_predict_level2(D, oracle, dev):
         else:
             outs = (locs.to(dev), confs.to(dev))
         alocs, ascores = m._activate(tuple(o.clone() for o in outs))
+        ref = torch_activation(m, tuple(o.cpu() for o in outs))
+        assert rel_close(ascores.cpu(), ref, 1e-5, atol=1e-9)
         want = oracle_select(O, ascores.cpu(), alocs.cpu(), m._anchors_for_decode(), m.decode_mode, m.class_begin,
                              m.class_id_offset, 0.01, 200)
         pb, ps, pc = m.pre_predict(tuple(o.clone() for o in outs))
@@ -359,6 +371,27 @@ def test_models_pre_predict_level2(D, oracle, dev):
         rid, rv = m.detect(tuple(o.clone() for o in outs), metas)
         wid, wv = O.predictor_run_rows(metas, pb, ps, pc, 0.45)
         assert torch.equal(rid.cpu(), wid) and torch.equal(rv.cpu(), wv)
+
+
+def test_fused_activation_selection_full_size(D, oracle, dev):
+    """RetinaNet-800 shapes with the soft-max fused into the one-pass selection: dense, sparse and
+    constant logits (every score equal: the sampled guess fails and the exact fallback must take over)."""
+    O = oracle
+    m = D.RetinaNet(80, [100, 50, 25, 13, 7])
+    P = m.pboxes.shape[0]
+    g = torch.Generator().manual_seed(31)
+    locs = torch.randn(3, P, 4, generator=g)
+    confs = torch.randn(3, P, 81, generator=g)
+    confs[1, :, 0] += 8.0
+    confs[2] = 0.25
+    outs = (locs.to(dev), confs.to(dev))
+    _, ascores = m._activate(outs)
+    assert rel_close(ascores.cpu(), torch.softmax(confs, -1), 1e-5, atol=1e-9)
+    want = oracle_select(O, ascores.cpu(), locs, m.pboxes, 0, 1, 0, 0.01, 1000)
+    m.return_cpu = True
+    pb, ps, pc = m.pre_predict(outs, 0.01, 1000)
+    check_select((pb, ps, pc), want)
+    assert pc[2].numel() == 80 * 1000 and int(torch.cat(pb[2:]).shape[0]) == 80000
 
 
 # ----------------------------------------------------------------------------- NMS
