@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     # argument validation happens before any device work, so it is testable here
     assert L.detbox_box_convert(None, None, -1, 0, 0, None) == -1
     assert b'negative' in L.detbox_last_error()
-    assert L.detbox_select_decode_workspace_bytes(16, 120087, 81, 1, 1000) > 16 * 80 * 1000 * 8
+    assert L.detbox_select_decode_workspace_bytes(16, 120087, 81, 1, 1000, 1) > 16 * 80 * 1000 * 8
     assert L.detbox_batched_nms_segments_workspace_bytes(2, 4000, 20) >= 2 * 2 * 4000 * 8
 
 
