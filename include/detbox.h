@@ -108,7 +108,7 @@ int detbox_assign_fcos(const float *points, const float *regress_ranges, int64_t
 
 /* Writes the activated scores out[B,P,C] of in[B,P,C] (extra [B,P] for the two activations that use
  * it).  The arithmetic is the one detbox_select_decode applies internally, bit for bit, so a caller
- * (or a test) can see exactly the scores the selection ranked.  Limit: C <= 512. */
+ * (or a test) can see exactly the scores the selection ranked.  Limit: C <= 256. */
 int detbox_activate_scores(int activation, const float *in, const float *extra, int64_t B, int64_t P, int64_t C,
                            float *out, void *stream);
 
@@ -181,6 +181,11 @@ int detbox_pack_detections(const float *boxes, const float *scores, const int64_
 int detbox_profile_enable(int on);
 int detbox_profile_reset(void);
 int detbox_profile_read(const char *name, double *total_ms, int64_t *launches);
+
+/* Measurement aid, not part of the box-ops path: reads in[0..n) once with 16-byte loads from `blocks`
+ * workgroups (kernel name "stream_read").  Its achieved GB/s is the read-bandwidth yardstick the
+ * streaming kernels are compared with. */
+int detbox_debug_stream_read(const float *in, int64_t n, float *out, int blocks, void *stream);
 
 #ifdef __cplusplus
 }

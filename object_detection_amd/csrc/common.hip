@@ -97,3 +97,27 @@ int detbox_profile_read(const char *name, double *total_ms, int64_t *launches) {
 }
 
 }  // extern "C"
+
+// ---- measurement aid: plain read-only stream (sum of a float buffer), the bandwidth yardstick ----
+namespace {
+__global__ __launch_bounds__(256) void stream_read_kernel(const float4 *__restrict__ in, size_t nvec, float *out) {
+    float acc = 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        const float4 a = in[i], b = in[i + stride], c = in[i + 2 * stride], d = in[i + 3 * stride];
+        acc += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) + (d.x + d.y + d.z + d.w);
+    }
+    for (; i < nvec; i += stride) { const float4 a = in[i]; acc += a.x + a.y + a.z + a.w; }
+    if (acc == 123456.789f) out[0] = acc;      // keeps the loads alive without a store in practice
+}
+}  // namespace
+
+extern "C" int detbox_debug_stream_read(const float *in, int64_t n, float *out, int blocks, void *stream) {
+    DETBOX_CHECK_ARG(in && out && n >= 0 && blocks > 0, "bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProfScope ps("stream_read", s);
+    stream_read_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(reinterpret_cast<const float4 *>(in), (size_t)n / 4, out);
+    DETBOX_LAUNCH_CHECK();
+    return DETBOX_OK;
+}

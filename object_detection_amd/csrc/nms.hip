@@ -86,13 +86,17 @@ __device__ inline unsigned long long uniform64(unsigned long long v) {
     return ((unsigned long long)hi << 32) | lo;
 }
 
+__device__ inline float readlane_f(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
 __device__ inline unsigned long long readlane64(unsigned long long v, int l) {
     const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l);
     const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
     return ((unsigned long long)hi << 32) | lo;
 }
 
-__global__ __launch_bounds__(NMS_BLOCK) void nms_segments_kernel(
+__global__ __launch_bounds__(NMS_BLOCK) void nms_segments_generic_kernel(
     const float4 *__restrict__ boxes, const float *__restrict__ scores, const int32_t *__restrict__ seg_off,
     NmsParams np, float2 *__restrict__ kept, int32_t *__restrict__ kcount, int32_t *__restrict__ err) {
     extern __shared__ unsigned long long s_dyn[];
@@ -228,6 +232,236 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_segments_kernel(
         if ((rem >> (i & 63)) & 1ull) continue;
         const uint32_t rank = s_wprefix[i >> 6] + (uint32_t)__popcll(~rem & ((1ull << (i & 63)) - 1ull));
         const int pos = seg0 + order_of(i);
+        kept[row0 + rank] = make_float2(scores[(size_t)b * np.stride + pos], __int_as_float(pos));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast path: unsorted segments of at most 256*JPT boxes, threshold >= 0.
+// Every thread keeps its JPT boxes (sorted positions tid, tid+256, ...) in registers for the whole
+// sweep; the boxes a chunk keeps are compacted into a small LDS array and broadcast, so one LDS read
+// serves JPT pair tests.  The pair test avoids the fp32 division: with u = (area_i + area_j) - inter
+// (the reference's own operations) and p = fl(thr * u),
+//     inter > p * (1 + 2^-21)  =>  fl(inter / u) > thr,     inter < p * (1 - 2^-21)  =>  fl(inter / u) <= thr
+// (the margins dominate the roundings of p and of the products), and only the sliver in between
+// -- or a tiny/non-positive p -- falls back to the reference's division.  Results are bit-identical.
+// ---------------------------------------------------------------------------------------------
+
+__device__ inline bool suppresses(const float4 bi, const float ai, const float4 bj, const float aj, const float thr) {
+    const float w = fminf(bi.z, bj.z) - fmaxf(bi.x, bj.x);
+    const float h = fminf(bi.w, bj.w) - fmaxf(bi.y, bj.y);
+    if (!(w > 0.0f && h > 0.0f)) return false;          // inter == 0 (or NaN): iou is 0 or NaN, never > thr >= 0
+    const float inter = w * h;
+    const float u = (ai + aj) - inter;
+    const float p = thr * u;
+    if (p > 1e-30f) {
+        if (inter > p * 1.0000005f) return true;
+        if (inter < p * 0.9999995f) return false;
+    }
+    return inter / u > thr;
+}
+
+struct NmsFastLds { size_t keys, box, area, kbox, karea, removed, maskq, misc, wprefix, total; };
+
+__host__ __device__ inline NmsFastLds nms_fast_lds(int max_seg, int n2) {
+    const size_t words_cap = (size_t)((max_seg + 63) >> 6);
+    NmsFastLds l;
+    size_t off = 0;
+    l.keys = off;    off += (size_t)n2 * 8;
+    l.box = off;     off += (size_t)max_seg * 16;
+    l.area = off;    off += (((size_t)max_seg * 4 + 15) & ~(size_t)15);
+    l.kbox = off;    off += 64 * 16;
+    l.karea = off;   off += 64 * 4;
+    l.removed = off; off += ((words_cap * 8 + 15) & ~(size_t)15);
+    l.maskq = off;   off += 256 * 8;
+    l.misc = off;    off += 16;                                       // keep word, kept count
+    l.wprefix = off; off += ((words_cap * 4 + 15) & ~(size_t)15);
+    l.total = off;
+    return l;
+}
+
+template <int JPT>
+__global__ __launch_bounds__(NMS_BLOCK) void nms_segments_fast_kernel(
+    const float4 *__restrict__ boxes, const float *__restrict__ scores, const int32_t *__restrict__ seg_off,
+    NmsParams np, float2 *__restrict__ kept, int32_t *__restrict__ kcount, int32_t *__restrict__ err) {
+    extern __shared__ unsigned long long s_dyn[];
+    const int s = blockIdx.x, b = blockIdx.y;
+    const int32_t *so = seg_off + (size_t)b * (np.S + 1);
+    const int seg0 = so[s];
+    const int n = so[s + 1] - seg0;
+    if (threadIdx.x == 0) kcount[(size_t)b * np.S + s] = 0;
+    if (n <= 0) return;
+    if (n > np.max_seg) {
+        if (threadIdx.x == 0) err[b] = 1;
+        return;
+    }
+    const NmsFastLds ld = nms_fast_lds(np.max_seg, np.n2);
+    char *lds_base = reinterpret_cast<char *>(s_dyn);
+    unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(lds_base + ld.keys);
+    float4 *s_box = reinterpret_cast<float4 *>(lds_base + ld.box);
+    float *s_area = reinterpret_cast<float *>(lds_base + ld.area);
+    float4 *s_kbox = reinterpret_cast<float4 *>(lds_base + ld.kbox);
+    float *s_karea = reinterpret_cast<float *>(lds_base + ld.karea);
+    unsigned long long *s_removed = reinterpret_cast<unsigned long long *>(lds_base + ld.removed);
+    unsigned long long *s_maskq = reinterpret_cast<unsigned long long *>(lds_base + ld.maskq);
+    unsigned long long *s_keepw = reinterpret_cast<unsigned long long *>(lds_base + ld.misc);
+    uint32_t *s_wprefix = reinterpret_cast<uint32_t *>(lds_base + ld.wprefix);
+
+    const size_t row0 = (size_t)b * np.stride + seg0;
+    const int tid = threadIdx.x;
+    const int words = (n + 63) >> 6;
+    const float thr = np.thr;
+
+    int n2 = 2;
+    while (n2 < n) n2 <<= 1;
+    for (int i = tid; i < n2; i += NMS_BLOCK) {
+        unsigned long long k = 0ull;
+        if (i < n)   // every real key is above the zero padding: its low word is 0xffffffff - i > 0
+            k = ((unsigned long long)okey_from_bits(__float_as_uint(scores[row0 + i])) << 32) |
+                (unsigned long long)(0xffffffffu - (uint32_t)i);
+        s_keys[i] = k;
+    }
+    __syncthreads();
+    bitonic_desc_u64(s_keys, n2);
+    // boxes in sorted order: LDS copy for the chunk phases, register copy of the thread's own boxes
+    float4 bj[JPT];
+    float aj[JPT];
+#pragma unroll
+    for (int m = 0; m < JPT; ++m) {
+        const int j = tid + m * NMS_BLOCK;
+        bj[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+        aj[m] = 0.f;
+        if (j < n) {
+            const int o = (int)(0xffffffffu - (uint32_t)(s_keys[j] & 0xffffffffull));
+            bj[m] = boxes[row0 + o];
+            aj[m] = (bj[m].z - bj[m].x) * (bj[m].w - bj[m].y);
+            s_box[j] = bj[m];
+            s_area[j] = aj[m];
+        }
+    }
+    for (int i = tid; i < words; i += NMS_BLOCK) s_removed[i] = 0ull;
+    __syncthreads();
+
+    unsigned rem_mask = 0u;                               // bit m: own box m is suppressed
+    const int lane = tid & 63, q = tid >> 6;
+    for (int ch = 0; ch < words; ++ch) {
+        const int c0 = ch << 6;
+        const int cn = min(64, n - c0);
+        const unsigned long long valid = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
+        const unsigned long long alive0 = ~s_removed[ch] & valid;
+        {   // 64x64 suppression words of this chunk: thread (lane, q) covers columns q*16..q*16+15
+            unsigned long long part = 0ull;
+            if (lane < cn && ((alive0 >> lane) & 1ull)) {
+                const float4 bi = s_box[c0 + lane];
+                const float ai = s_area[c0 + lane];
+                const int j0 = max(q * 16, lane + 1), j1 = min(q * 16 + 16, cn);
+                for (int j = j0; j < j1; ++j)
+                    if (suppresses(bi, ai, s_box[c0 + j], s_area[c0 + j], thr)) part |= 1ull << j;
+            }
+            s_maskq[q * 64 + lane] = part;
+        }
+        __syncthreads();
+        if (q == 0) {
+            const unsigned long long m = s_maskq[lane] | s_maskq[64 + lane] | s_maskq[128 + lane] | s_maskq[192 + lane];
+            unsigned long long alive = uniform64(alive0);
+            unsigned long long keep = 0ull;
+            while (alive) {
+                const int i = __ffsll((long long)alive) - 1;
+                keep |= 1ull << i;
+                alive &= ~readlane64(m, i);
+                alive &= ~(1ull << i);
+            }
+            if ((keep >> lane) & 1ull) {                  // compact the kept boxes of the chunk
+                const int r = __popcll(keep & ((1ull << lane) - 1ull));
+                s_kbox[r] = s_box[c0 + lane];
+                s_karea[r] = s_area[c0 + lane];
+            }
+            if (lane == 0) { s_keepw[0] = keep; s_removed[ch] = valid & ~keep; }
+        }
+        __syncthreads();
+        const int nk = __popcll(s_keepw[0]);
+        // The kept boxes of this chunk against every later box still alive.  The later boxes are the
+        // lanes' own register boxes; kept box t is broadcast with readlane from a register image of the
+        // kept list; which lanes are still alive is a wave-uniform 64-bit mask per register slot, so
+        // all bookkeeping is scalar and a slot whose lanes are all settled is skipped.
+        if (nk > 0) {
+            const float4 kb = lane < nk ? s_kbox[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float ka = lane < nk ? s_karea[lane] : 0.f;
+            unsigned long long act[JPT];
+            bool any_act = false;
+#pragma unroll
+            for (int m = 0; m < JPT; ++m) {
+                const int j = tid + m * NMS_BLOCK;
+                act[m] = __ballot(j >= c0 + 64 && j < n && !((rem_mask >> m) & 1u));
+                any_act |= act[m] != 0ull;
+            }
+            if (any_act) {
+                unsigned long long hit[JPT];
+#pragma unroll
+                for (int m = 0; m < JPT; ++m) hit[m] = 0ull;
+                for (int t = 0; t < nk; ++t) {
+                    const float ix1 = readlane_f(kb.x, t), iy1 = readlane_f(kb.y, t);
+                    const float ix2 = readlane_f(kb.z, t), iy2 = readlane_f(kb.w, t);
+                    const float ai = readlane_f(ka, t);
+#pragma unroll
+                    for (int m = 0; m < JPT; ++m) {
+                        if (act[m]) {                                   // wave-uniform
+                            const float w = fmaxf(fminf(ix2, bj[m].z) - fmaxf(ix1, bj[m].x), 0.0f);
+                            const float h = fmaxf(fminf(iy2, bj[m].w) - fmaxf(iy1, bj[m].y), 0.0f);
+                            const float inter = w * h;
+                            const float u = (ai + aj[m]) - inter;
+                            const float p = thr * u;
+                            const unsigned long long sane = __ballot(p > 1e-30f);
+                            unsigned long long yes = __ballot(inter > p * 1.0000005f) & sane;
+                            const unsigned long long no = __ballot(inter < p * 0.9999995f) & sane;
+                            const unsigned long long amb = act[m] & ~(yes | no);
+                            if (amb) yes |= __ballot(inter / u > thr) & amb;   // the sliver the margins leave
+                            yes &= act[m];
+                            act[m] &= ~yes;
+                            hit[m] |= yes;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < JPT; ++m) {
+                    if ((hit[m] >> lane) & 1ull) {
+                        const int j = tid + m * NMS_BLOCK;
+                        rem_mask |= 1u << m;
+                        atomicOr(&s_removed[j >> 6], 1ull << (j & 63));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // kept = not removed; compact in sorted order
+    if (q == 0) {
+        uint32_t running = 0;
+        for (int base = 0; base < words; base += 64) {
+            const int w = base + lane;
+            uint32_t pc = 0;
+            if (w < words) {
+                const int cn = min(64, n - (w << 6));
+                const unsigned long long valid = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
+                pc = (uint32_t)__popcll(~s_removed[w] & valid);
+            }
+            uint32_t inc = pc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(inc, o);
+                if (lane >= o) inc += up;
+            }
+            if (w < words) s_wprefix[w] = running + inc - pc;
+            running += __shfl(inc, 63);
+        }
+        if (lane == 0) kcount[(size_t)b * np.S + s] = (int32_t)running;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += NMS_BLOCK) {
+        const unsigned long long rem = s_removed[i >> 6];
+        if ((rem >> (i & 63)) & 1ull) continue;
+        const uint32_t rank = s_wprefix[i >> 6] + (uint32_t)__popcll(~rem & ((1ull << (i & 63)) - 1ull));
+        const int pos = seg0 + (int)(0xffffffffu - (uint32_t)(s_keys[i] & 0xffffffffull));
         kept[row0 + rank] = make_float2(scores[(size_t)b * np.stride + pos], __int_as_float(pos));
     }
 }
@@ -391,14 +625,34 @@ extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scor
     if ((double)t32 > iou_threshold) t32 = std::nextafterf(t32, -INFINITY);
     np.thr = t32;
     np.thr_neg = iou_threshold < 0.0 ? 1 : 0;
-    const size_t lds = nms_lds(np.max_seg, np.n2, np.presorted, np.in_lds).total;
+    const bool fast = !np.presorted && !np.thr_neg && max_segment <= DETBOX_NMS_MAX_SORT;
     {
         ProfScope ps("nms_segments", st);
-        if (lds > 64 * 1024)
-            DETBOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_segments_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        nms_segments_kernel<<<dim3((unsigned)S, (unsigned)B), dim3(NMS_BLOCK), lds, st>>>(
-            reinterpret_cast<const float4 *>(boxes), scores, seg_offsets, np, kept_a, kcount, err);
+        dim3 grid((unsigned)S, (unsigned)B);
+        const float4 *b4 = reinterpret_cast<const float4 *>(boxes);
+        if (fast) {
+            const size_t lds = nms_fast_lds(np.max_seg, np.n2).total;
+#define DETBOX_NMS_FAST(J)                                                                                       \
+    {                                                                                                            \
+        if (lds > 64 * 1024)                                                                                     \
+            DETBOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_segments_fast_kernel<J>),          \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
+        nms_segments_fast_kernel<J><<<grid, dim3(NMS_BLOCK), lds, st>>>(b4, scores, seg_offsets, np, kept_a, kcount, err); \
+    }
+            const int jpt = (int)((max_segment + NMS_BLOCK - 1) / NMS_BLOCK);
+            if (jpt <= 1) DETBOX_NMS_FAST(1)
+            else if (jpt <= 2) DETBOX_NMS_FAST(2)
+            else if (jpt <= 4) DETBOX_NMS_FAST(4)
+            else if (jpt <= 8) DETBOX_NMS_FAST(8)
+            else DETBOX_NMS_FAST(16)
+#undef DETBOX_NMS_FAST
+        } else {
+            const size_t lds = nms_lds(np.max_seg, np.n2, np.presorted, np.in_lds).total;
+            if (lds > 64 * 1024)
+                DETBOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_segments_generic_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            nms_segments_generic_kernel<<<grid, dim3(NMS_BLOCK), lds, st>>>(b4, scores, seg_offsets, np, kept_a, kcount, err);
+        }
         DETBOX_LAUNCH_CHECK();
     }
     {

@@ -40,8 +40,9 @@ constexpr int MAX_SEL_CLASSES = 128;  // LDS tables are sized for this many sele
 constexpr int MAX_TILE_ANCHORS = 16384;
 constexpr int SUB_ROWS = 64;          // anchors per LDS sub-tile (4 lanes per anchor row)
 constexpr int SCAN_BLOCK = 256;
-constexpr int LCAP = 1024;            // block-local candidate list (entries)
-constexpr int SAMPLE_SUBS = 8;        // sampled sub-tiles per block of select_sample
+constexpr int LCAP = 3072;            // block-local candidate list (entries)
+constexpr int LFLUSH = 2048;          // flush the list to the staging lists beyond this many entries
+constexpr int SAMPLE_SUBS = 2;        // sampled sub-tiles per block of select_sample (8-bit LDS counters: <= 3)
 constexpr int BITMAP_MAX_WORDS = 4096;  // finalize orders by anchor through a P-bit LDS bitmap up to this
 
 enum { ACT_NONE = 0, ACT_SOFTMAX = 1, ACT_SOFTMAX_SIGMOID = 2, ACT_SIGMOID_SIGMOID = 3 };
@@ -60,6 +61,7 @@ struct SelRule {
 struct SelParams {
     int P, C, cb, Cs, top_k, cap, shift, tile_anchors;
     int use_sample, sample_rate, sample_m, subs_per_block, n_sub, tile_floats;
+    long long total_floats;
     float thr;
     uint32_t key_thr;
 };
@@ -95,66 +97,133 @@ __device__ inline float quad_sum(float v) {
 }
 __device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// Stages rows [row_base, row_base+rows) x C of `in` into LDS with coalesced 16-byte loads (the
-// LDS image starts `shift` floats in, so that every load and LDS store is 16-byte aligned), applies
-// the activation and calls f(score, class, local_row) for every element.  Block = SCAN_BLOCK threads.
+// One sub-tile = rows [row_base, row_base+rows) x C of the head output.  It is brought into LDS by
+// LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, no staging registers); the LDS
+// image starts `shift` floats in, so that every 16-byte piece is aligned in both memories.  Two LDS
+// buffers alternate: the DMA of sub-tile s+1 is in flight while sub-tile s is being consumed, and one
+// barrier per sub-tile (which also drains the DMA) separates the roles.  Four lanes share an anchor
+// row; a lane keeps its EPT = ceil(C/4) elements in registers for the whole soft-max.
 //   ACT_SOFTMAX          score = exp(x - max) / sum                    (ssd300.py:354, retinanet.py:282)
 //   ACT_SOFTMAX_SIGMOID  score = softmax(x) * sigmoid(extra[row])      (fcos.py:314)
 //   ACT_SIGMOID_SIGMOID  score = sigmoid(x) * sigmoid(extra[row])      (yolov3.py:298-300)
-template <int ACT, typename F>
-__device__ inline void activate_subtile(const float *__restrict__ in, const float *__restrict__ extra,
-                                        long long row_base, int rows, int C, float *s_tile, F f) {
-    const int tid = threadIdx.x;
+struct SubGeom {
+    const float *src;     // 16-byte aligned start of the pieces
+    long long abs0;       // float index of src inside the tensor
+    int shift, nfl, nvec;
+};
+
+__device__ inline SubGeom sub_geom(const float *in, long long row_base, int rows, int C) {
+    SubGeom g;
     const long long f0 = row_base * C;
-    const int shift = (int)(f0 & 3);
-    const float *src = in + (f0 - shift);
-    const int nfl = rows * C + shift;
-    const int nvec = (nfl + 3) >> 2;
-    for (int v = tid; v < nvec; v += SCAN_BLOCK) {
-        float4 x;
-        if (4 * v + 4 <= nfl) {
-            x = reinterpret_cast<const float4 *>(src)[v];
-        } else {                                   // last vector: never read past the tile
-            x.x = src[4 * v];
-            x.y = (4 * v + 1 < nfl) ? src[4 * v + 1] : 0.f;
-            x.z = (4 * v + 2 < nfl) ? src[4 * v + 2] : 0.f;
-            x.w = 0.f;
-        }
-        reinterpret_cast<float4 *>(s_tile)[v] = x;
-    }
-    __syncthreads();
-    const int r = tid >> 2, sub = tid & 3;
-    if (r < rows) {
-        float *row = s_tile + shift + r * C;
-        if (ACT == ACT_SOFTMAX || ACT == ACT_SOFTMAX_SIGMOID) {
-            float m = -__builtin_inff();
-            for (int c = sub; c < C; c += 4) m = fmaxf(m, row[c]);
-            m = quad_max(m);
-            float sum = 0.f;
-            for (int c = sub; c < C; c += 4) {
-                const float e = __expf(row[c] - m);
-                row[c] = e;
-                sum += e;
-            }
-            sum = quad_sum(sum);
-            const float inv = 1.0f / sum;
-            if (ACT == ACT_SOFTMAX_SIGMOID) {
-                const float sg = sigmoidf_(extra[row_base + r]);
-                for (int c = sub; c < C; c += 4) f((row[c] * inv) * sg, c, r);
-            } else {
-                for (int c = sub; c < C; c += 4) f(row[c] * inv, c, r);
-            }
-        } else if (ACT == ACT_SIGMOID_SIGMOID) {
-            const float so = sigmoidf_(extra[row_base + r]);
-            for (int c = sub; c < C; c += 4) f(sigmoidf_(row[c]) * so, c, r);
-        } else {
-            for (int c = sub; c < C; c += 4) f(row[c], c, r);
-        }
-    }
-    __syncthreads();
+    g.shift = (int)(f0 & 3);
+    g.abs0 = f0 - g.shift;
+    g.src = in + g.abs0;
+    g.nfl = rows * C + g.shift;
+    g.nvec = (g.nfl + 3) >> 2;
+    return g;
 }
 
-template <int ACT>
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+template <int EPT>
+__device__ inline void dma_issue(const SubGeom &g, float *s_buf, long long total_floats) {
+    const int tid = threadIdx.x, wbase = tid & ~63;
+#pragma unroll
+    for (int j = 0; j < EPT / 4 + 1; ++j) {
+        const int v = tid + j * SCAN_BLOCK;
+        if (v < g.nvec) {
+            if (g.abs0 + 4ll * v + 4 <= total_floats) {
+                // LDS destination = wave-uniform base + lane * 16
+                __builtin_amdgcn_global_load_lds((gptr_t)(g.src + 4 * v), (lptr_t)(s_buf + 4 * (wbase + j * SCAN_BLOCK)), 16, 0, 0);
+            } else {                                   // the last piece of the whole tensor: stay inside it
+                for (int q = 0; q < 4; ++q)
+                    if (g.abs0 + 4ll * v + q < total_floats) s_buf[4 * v + q] = g.src[4 * v + q];
+            }
+        }
+    }
+}
+
+// Scores of this lane's elements of the sub-tile sitting in LDS: x[i] = score of class sub + 4*i of
+// local row threadIdx.x / 4 (meaningless for classes >= C).  Returns false for lanes beyond `rows`.
+template <int ACT, int EPT>
+__device__ inline bool subtile_scores(const float *s_tile, const float *__restrict__ extra, long long row_base,
+                                      int rows, int C, int shift, float (&x)[EPT]) {
+    const int r = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    if (r >= rows) return false;
+    const float *row = s_tile + shift + r * C + sub;     // the tile has 4*EPT floats of slack behind it
+    const float fill = (ACT == ACT_SOFTMAX || ACT == ACT_SOFTMAX_SIGMOID) ? -__builtin_inff() : 0.f;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const float v = row[4 * i];
+        x[i] = (sub + 4 * i < C) ? v : fill;
+    }
+    if (ACT == ACT_SOFTMAX || ACT == ACT_SOFTMAX_SIGMOID) {
+        float m = x[0];
+#pragma unroll
+        for (int i = 1; i < EPT; ++i) m = fmaxf(m, x[i]);
+        m = quad_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            x[i] = __expf(x[i] - m);
+            sum += x[i];
+        }
+        sum = quad_sum(sum);
+        const float inv = 1.0f / sum;
+        if (ACT == ACT_SOFTMAX_SIGMOID) {
+            const float sg = sigmoidf_(extra[row_base + r]);
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) x[i] = (x[i] * inv) * sg;
+        } else {
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) x[i] = x[i] * inv;
+        }
+    } else if (ACT == ACT_SIGMOID_SIGMOID) {
+        const float so = sigmoidf_(extra[row_base + r]);
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) x[i] = sigmoidf_(x[i]) * so;
+    }
+    return true;
+}
+
+// Runs f(x, valid, first_anchor_of_subtile) over sub-tiles first, first+step, ... (< last) of image b
+// with the double-buffered DMA pipeline; after(s) runs once per sub-tile behind the barrier
+// (block-uniform work such as a flush).  s_tiles holds two buffers of tile_floats floats.
+template <int ACT, int EPT, typename F, typename G>
+__device__ inline void for_each_subtile(const float *__restrict__ in, const float *__restrict__ extra, int b, int P,
+                                        int C, long long total_floats, long long first, long long last,
+                                        long long step, float *s_tiles, int tile_floats, F f, G after) {
+    if (first >= last) return;
+    auto geom = [&](long long s) {
+        const int r0 = (int)s * SUB_ROWS;
+        return sub_geom(in, (long long)b * P + r0, min(SUB_ROWS, P - r0), C);
+    };
+    SubGeom g = geom(first);
+    int buf = 0;
+    dma_issue<EPT>(g, s_tiles, total_floats);
+    __syncthreads();
+    for (long long s = first; s < last; s += step) {
+        const bool more = s + step < last;
+        SubGeom gn = g;
+        if (more) {
+            gn = geom(s + step);
+            dma_issue<EPT>(gn, s_tiles + (buf ^ 1) * tile_floats, total_floats);
+        }
+        const int r0 = (int)s * SUB_ROWS;
+        const int rows = min(SUB_ROWS, P - r0);
+        float x[EPT];
+        const bool valid = subtile_scores<ACT, EPT>(s_tiles + buf * tile_floats, extra, (long long)b * P + r0, rows, C,
+                                                    g.shift, x);
+        f(x, valid, r0);
+        __syncthreads();          // sub-tile s consumed by every wave, DMA of the next one landed
+        after(s);
+        g = gn;
+        buf ^= 1;
+    }
+}
+
+template <int ACT, int EPT>
 __global__ __launch_bounds__(SCAN_BLOCK) void activate_scores_kernel(const float *__restrict__ in,
                                                                      const float *__restrict__ extra, SelParams sp,
                                                                      const uint32_t *__restrict__ flag,
@@ -162,56 +231,62 @@ __global__ __launch_bounds__(SCAN_BLOCK) void activate_scores_kernel(const float
     extern __shared__ float s_dynf[];
     if (flag && *flag == 0u) return;
     const int b = blockIdx.y;
-    const int sub0 = blockIdx.x * sp.subs_per_block;
-    const int sub1 = min(sp.n_sub, sub0 + sp.subs_per_block);
-    for (int s = sub0; s < sub1; ++s) {
-        const int r0 = s * SUB_ROWS;
-        const int rows = min(SUB_ROWS, sp.P - r0);
-        const long long row_base = (long long)b * sp.P + r0;
-        float *o = out + row_base * sp.C;
-        const int C = sp.C;
-        activate_subtile<ACT>(in, extra, row_base, rows, C, s_dynf, [&](float sc, int c, int r) { o[r * C + c] = sc; });
-    }
+    const long long sub0 = (long long)blockIdx.x * sp.subs_per_block;
+    const long long sub1 = min((long long)sp.n_sub, sub0 + sp.subs_per_block);
+    float *o = out + (size_t)b * sp.P * sp.C;
+    const int C = sp.C;
+    const int r = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    for_each_subtile<ACT, EPT>(in, extra, b, sp.P, C, sp.total_floats, sub0, sub1, 1, s_dynf, sp.tile_floats,
+                               [&](float (&x)[EPT], bool valid, int r0) {
+                                   if (!valid) return;
+                                   float *orow = o + (size_t)(r0 + r) * C + sub;
+#pragma unroll
+                                   for (int i = 0; i < EPT; ++i)
+                                       if (sub + 4 * i < C) orow[4 * i] = x[i];
+                               },
+                               [](long long) {});
 }
 
 // ---------------------------------------------------------------------------------------------
 // Fast path
 // ---------------------------------------------------------------------------------------------
 
-template <int ACT>
+template <int ACT, int EPT>
 __global__ __launch_bounds__(SCAN_BLOCK) void select_sample_kernel(const float *__restrict__ in,
                                                                    const float *__restrict__ extra, SelParams sp,
                                                                    uint32_t *__restrict__ shist) {
     extern __shared__ float s_dynf[];
-    float *s_tile = s_dynf;
-    uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_dynf + sp.tile_floats);   // [Cs][NB/2] packed 16-bit
+    // [Cs][NB/4] words of four 8-bit counters: a block sees SAMPLE_SUBS*64 <= 128 rows, so no counter overflows
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_dynf + 2 * sp.tile_floats);
     const int b = blockIdx.y;
-    const int words = sp.Cs * (NB / 2);
+    const int words = sp.Cs * (NB / 4);
     for (int i = threadIdx.x; i < words; i += SCAN_BLOCK) s_hist[i] = 0u;
     __syncthreads();
     const float thr = sp.thr;
     const uint32_t key_thr = sp.key_thr;
-    const int shift = sp.shift, cb = sp.cb;
-    for (int i = 0; i < SAMPLE_SUBS; ++i) {
-        const long long s = (long long)(blockIdx.x * SAMPLE_SUBS + i) * sp.sample_rate;
-        if (s >= sp.n_sub) break;
-        const int r0 = (int)s * SUB_ROWS;
-        const int rows = min(SUB_ROWS, sp.P - r0);
-        activate_subtile<ACT>(in, extra, (long long)b * sp.P + r0, rows, sp.C, s_tile, [&](float sc, int c, int) {
-            if (c >= cb && sc > thr) {
-                const uint32_t bin = bin_of(okey(sc) - key_thr, shift);
-                atomicAdd(&s_hist[(c - cb) * (NB / 2) + (bin >> 1)], 1u << ((bin & 1u) * 16u));
-            }
-        });
-    }
+    const int shift = sp.shift, cb = sp.cb, C = sp.C;
+    const int sub = threadIdx.x & 3;
+    const long long first = (long long)blockIdx.x * SAMPLE_SUBS * sp.sample_rate;
+    const long long last = min((long long)sp.n_sub, first + (long long)SAMPLE_SUBS * sp.sample_rate);
+    for_each_subtile<ACT, EPT>(in, extra, b, sp.P, C, sp.total_floats, first, last, sp.sample_rate, s_dynf, sp.tile_floats,
+                               [&](float (&x)[EPT], bool valid, int) {
+                                   if (!valid) return;
+#pragma unroll
+                                   for (int i = 0; i < EPT; ++i) {
+                                       const int c = sub + 4 * i;
+                                       if (c >= cb && c < C && x[i] > thr) {
+                                           const uint32_t bin = bin_of(okey(x[i]) - key_thr, shift);
+                                           atomicAdd(&s_hist[(c - cb) * (NB / 4) + (bin >> 2)], 1u << ((bin & 3u) * 8u));
+                                       }
+                                   }
+                               },
+                               [](long long) {});
     uint32_t *gh = shist + (size_t)b * sp.Cs * NB;
     for (int i = threadIdx.x; i < words; i += SCAN_BLOCK) {
-        const uint32_t v = s_hist[i];
-        if (v) {
-            const uint32_t lo = v & 0xffffu, hi = v >> 16;
-            if (lo) atomicAdd(&gh[2 * i], lo);
-            if (hi) atomicAdd(&gh[2 * i + 1], hi);
-        }
+        uint32_t v = s_hist[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q, v >>= 8)
+            if (v & 0xffu) atomicAdd(&gh[4 * i + q], v & 0xffu);
     }
 }
 
@@ -246,102 +321,119 @@ __device__ inline void find_kth_bin(uint4 q, uint32_t suf, uint32_t t, int lane,
 
 __global__ __launch_bounds__(256) void select_plan_kernel(const uint32_t *__restrict__ shist, SelParams sp,
                                                           SelRule *__restrict__ rules, uint32_t *__restrict__ flag) {
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    for (int ci = wave; ci < sp.Cs; ci += nwaves) {
-        SelRule r;
-        r.pad = 0; r.cutoff = 0ull; r.n_above = 0; r.n_sel = 0;
-        if (!sp.use_sample) {
-            r.mode = RULE_PENDING; r.beta = 0; r.min_score = __builtin_inff();
-        } else {
-            const uint32_t *h = shist + ((size_t)b * sp.Cs + ci) * NB;
-            const uint4 q = reinterpret_cast<const uint4 *>(h)[lane];
-            const uint32_t t = q.x + q.y + q.z + q.w;
-            const uint32_t suf = suffix_scan64(t, lane);
-            const uint32_t total = __shfl(suf, 0);
-            r.mode = RULE_STAGED;
-            unsigned long long dmin = 1ull;
-            if (total > (uint32_t)sp.sample_m) {
-                uint32_t beta, n_above, n_beta;
-                find_kth_bin(q, suf, t, lane, (uint32_t)sp.sample_m, beta, n_above, n_beta);
-                dmin = (unsigned long long)beta << sp.shift;
-                if (dmin < 1ull) dmin = 1ull;
-            }
-            r.beta = dmin == 1ull ? 1u : 0u;            // 1: everything above the threshold gets staged
-            r.min_score = score_from_d(sp.key_thr, dmin);
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int ci = blockIdx.x * 4 + (threadIdx.x >> 6);          // one wave per (image, class)
+    if (!sp.use_sample && b == 0 && blockIdx.x == 0 && threadIdx.x == 0) *flag = 1u;
+    if (ci >= sp.Cs) return;
+    SelRule r;
+    r.pad = 0; r.cutoff = 0ull; r.n_above = 0; r.n_sel = 0;
+    if (!sp.use_sample) {
+        r.mode = RULE_PENDING; r.beta = 0; r.min_score = __builtin_inff();
+    } else {
+        const uint32_t *h = shist + ((size_t)b * sp.Cs + ci) * NB;
+        const uint4 q = reinterpret_cast<const uint4 *>(h)[lane];
+        const uint32_t t = q.x + q.y + q.z + q.w;
+        const uint32_t suf = suffix_scan64(t, lane);
+        const uint32_t total = __shfl(suf, 0);
+        r.mode = RULE_STAGED;
+        unsigned long long dmin = 1ull;
+        if (total > (uint32_t)sp.sample_m) {
+            uint32_t beta, n_above, n_beta;
+            find_kth_bin(q, suf, t, lane, (uint32_t)sp.sample_m, beta, n_above, n_beta);
+            dmin = (unsigned long long)beta << sp.shift;
+            if (dmin < 1ull) dmin = 1ull;
         }
-        if (lane == 0) rules[(size_t)b * sp.Cs + ci] = r;
+        r.beta = dmin == 1ull ? 1u : 0u;            // 1: everything above the threshold gets staged
+        r.min_score = score_from_d(sp.key_thr, dmin);
     }
-    if (!sp.use_sample && b == 0 && threadIdx.x == 0) *flag = 1u;
+    if (lane == 0) rules[(size_t)b * sp.Cs + ci] = r;
 }
 
-template <int ACT>
+template <int ACT, int EPT>
 __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__restrict__ in,
                                                                  const float *__restrict__ extra, SelParams sp,
                                                                  const SelRule *__restrict__ rules,
                                                                  uint32_t *__restrict__ gcnt,
                                                                  unsigned long long *__restrict__ staging) {
     extern __shared__ float s_dynf[];
-    float *s_tile = s_dynf;
-    unsigned long long *s_lk = reinterpret_cast<unsigned long long *>(s_dynf + sp.tile_floats);   // [LCAP]
-    uint32_t *s_lmeta = reinterpret_cast<uint32_t *>(s_lk + LCAP);                                // [LCAP]
-    float *s_tlo = reinterpret_cast<float *>(s_lmeta + LCAP);                                     // [MAX_SEL_CLASSES]
-    uint32_t *s_ccount = reinterpret_cast<uint32_t *>(s_tlo + MAX_SEL_CLASSES);
+    unsigned long long *s_lk = reinterpret_cast<unsigned long long *>(s_dynf + 2 * sp.tile_floats);   // [LCAP]
+    uint32_t *s_lmeta = reinterpret_cast<uint32_t *>(s_lk + LCAP);                                    // [LCAP]
+    uint32_t *s_ccount = s_lmeta + LCAP;                                                              // [MAX_SEL_CLASSES]
     uint32_t *s_cbase = s_ccount + MAX_SEL_CLASSES;
     uint32_t *s_n = s_cbase + MAX_SEL_CLASSES;
 
     const int b = blockIdx.y, tid = threadIdx.x;
-    const int Cs = sp.Cs, cb = sp.cb, cap = sp.cap;
+    const int Cs = sp.Cs, cb = sp.cb, cap = sp.cap, C = sp.C;
     const uint32_t key_thr = sp.key_thr;
     const SelRule *rb = rules + (size_t)b * Cs;
     uint32_t *gc = gcnt + (size_t)b * Cs;
     unsigned long long *stg = staging + (size_t)b * Cs * cap;
-    if (tid < Cs) s_tlo[tid] = rb[tid].mode == RULE_STAGED ? rb[tid].min_score : __builtin_inff();
+    // the lane's classes never change: their staging thresholds live in registers
+    const int r = tid >> 2, sub = tid & 3;
+    float tlo[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int c = sub + 4 * i;
+        tlo[i] = (c >= cb && c < C && rb[c - cb].mode == RULE_STAGED) ? rb[c - cb].min_score : __builtin_inff();
+    }
     if (tid == 0) *s_n = 0u;
     __syncthreads();
 
-    const int sub0 = blockIdx.x * sp.subs_per_block;
-    const int sub1 = min(sp.n_sub, sub0 + sp.subs_per_block);
-    for (int s = sub0; s < sub1; ++s) {
-        const int r0 = s * SUB_ROWS;
-        const int rows = min(SUB_ROWS, sp.P - r0);
-        activate_subtile<ACT>(in, extra, (long long)b * sp.P + r0, rows, sp.C, s_tile, [&](float sc, int c, int r) {
-            if (c >= cb && sc >= s_tlo[c - cb]) {
-                const int ci = c - cb;
-                const unsigned long long K = make_key(sc, key_thr, (uint32_t)(r0 + r));
-                const uint32_t slot = atomicAdd(s_n, 1u);
-                if (slot < (uint32_t)LCAP) {
-                    s_lk[slot] = K;
-                    s_lmeta[slot] = (uint32_t)ci;
-                } else {                                  // block list full: straight to the staging list
-                    const uint32_t g = atomicAdd(&gc[ci], 1u);
-                    if (g < (uint32_t)cap) stg[(size_t)ci * cap + g] = K;
+    const long long sub0 = (long long)blockIdx.x * sp.subs_per_block;
+    const long long sub1 = min((long long)sp.n_sub, sub0 + sp.subs_per_block);
+    for_each_subtile<ACT, EPT>(
+        in, extra, b, sp.P, C, sp.total_floats, sub0, sub1, 1, s_dynf, sp.tile_floats,
+        [&](float (&x)[EPT], bool valid, int r0) {
+            unsigned long long pm = 0ull;               // bit i: element i is staged
+            if (valid) {
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) pm |= (unsigned long long)(x[i] >= tlo[i]) << i;
+            }
+            if (pm) {                                   // one LDS reservation per lane with candidates
+                uint32_t slot = atomicAdd(s_n, (uint32_t)__popcll(pm));
+                const uint32_t p = (uint32_t)(r0 + r);
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) {
+                    if ((pm >> i) & 1ull) {
+                        const int ci = sub + 4 * i - cb;
+                        const unsigned long long K = make_key(x[i], key_thr, p);
+                        if (slot < (uint32_t)LCAP) {
+                            s_lk[slot] = K;
+                            s_lmeta[slot] = (uint32_t)ci;
+                        } else {                          // block list full: straight to the staging list
+                            const uint32_t g = atomicAdd(&gc[ci], 1u);
+                            if (g < (uint32_t)cap) stg[(size_t)ci * cap + g] = K;
+                        }
+                        ++slot;
+                    }
                 }
             }
+        },
+        [&](long long s) {
+            const uint32_t n_raw = *s_n;                  // block-uniform: read behind a barrier
+            if (n_raw > (uint32_t)LFLUSH || s == sub1 - 1) {
+                const int n = (int)min(n_raw, (uint32_t)LCAP);
+                if (tid < MAX_SEL_CLASSES) s_ccount[tid] = 0u;
+                __syncthreads();
+                for (int e = tid; e < n; e += SCAN_BLOCK) {
+                    const uint32_t ci = s_lmeta[e];
+                    s_lmeta[e] = ci | (atomicAdd(&s_ccount[ci], 1u) << 16);
+                }
+                __syncthreads();
+                if (tid < Cs && s_ccount[tid]) s_cbase[tid] = atomicAdd(&gc[tid], s_ccount[tid]);
+                __syncthreads();
+                for (int e = tid; e < n; e += SCAN_BLOCK) {
+                    const uint32_t meta = s_lmeta[e];
+                    const uint32_t ci = meta & 0xffffu;
+                    const uint32_t pos = s_cbase[ci] + (meta >> 16);
+                    if (pos < (uint32_t)cap) stg[(size_t)ci * cap + pos] = s_lk[e];
+                }
+                __syncthreads();
+                if (tid == 0) *s_n = 0u;
+                __syncthreads();
+            }
         });
-        const uint32_t n_raw = *s_n;                      // uniform: activate_subtile ended with a barrier
-        if (n_raw > (uint32_t)(LCAP / 2) || s == sub1 - 1) {
-            const int n = (int)min(n_raw, (uint32_t)LCAP);
-            if (tid < MAX_SEL_CLASSES) s_ccount[tid] = 0u;
-            __syncthreads();
-            for (int e = tid; e < n; e += SCAN_BLOCK) {
-                const uint32_t ci = s_lmeta[e];
-                s_lmeta[e] = ci | (atomicAdd(&s_ccount[ci], 1u) << 16);
-            }
-            __syncthreads();
-            if (tid < Cs && s_ccount[tid]) s_cbase[tid] = atomicAdd(&gc[tid], s_ccount[tid]);
-            __syncthreads();
-            for (int e = tid; e < n; e += SCAN_BLOCK) {
-                const uint32_t meta = s_lmeta[e];
-                const uint32_t ci = meta & 0xffffu;
-                const uint32_t pos = s_cbase[ci] + (meta >> 16);
-                if (pos < (uint32_t)cap) stg[(size_t)ci * cap + pos] = s_lk[e];
-            }
-            __syncthreads();
-            if (tid == 0) *s_n = 0u;
-            __syncthreads();
-        }
-    }
 }
 
 __global__ __launch_bounds__(128) void select_check_kernel(SelParams sp, SelRule *__restrict__ rules,
@@ -435,12 +527,17 @@ __global__ __launch_bounds__(256) void select_kth_kernel(const uint32_t *__restr
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const uint32_t k = (uint32_t)sp.top_k;
+    __shared__ uint32_t s_pending[MAX_SEL_CLASSES];
+    if (threadIdx.x < sp.Cs) {                       // Cs <= MAX_SEL_CLASSES <= blockDim
+        const SelRule *rp = rules + (size_t)b * sp.Cs + threadIdx.x;
+        const uint32_t mode = rp->mode;
+        s_pending[threadIdx.x] = mode == RULE_PENDING ? 1u : 0u;
+        s_nsel[threadIdx.x] = (int)rp->n_sel;
+    }
+    __syncthreads();
     for (int ci = wave; ci < sp.Cs; ci += nwaves) {
+        if (!s_pending[ci]) continue;
         SelRule *rp = rules + (size_t)b * sp.Cs + ci;
-        if (rp->mode != RULE_PENDING) {
-            if (lane == 0) s_nsel[ci] = (int)rp->n_sel;
-            continue;
-        }
         const uint32_t *h = ghist + ((size_t)b * sp.Cs + ci) * NB;
         const uint4 q = reinterpret_cast<const uint4 *>(h)[lane];       // bins 4*lane .. 4*lane+3
         const uint32_t t = q.x + q.y + q.z + q.w;
@@ -611,36 +708,14 @@ __device__ inline float4 decode_box(const float *__restrict__ anchors, float4 l,
     }
 }
 
-// The n_sel-th largest of the n distinct keys in s_k, by most-significant-digit radix search.
-__device__ inline unsigned long long radix_kth_largest(const unsigned long long *s_k, int n, uint32_t n_sel,
-                                                       uint32_t *s_h, unsigned long long *s_pref, uint32_t *s_rem) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    if (tid == 0) { *s_pref = 0ull; *s_rem = n_sel; }
-    __syncthreads();
-    for (int shift = 56; shift >= 0; shift -= 8) {
-        const unsigned long long pref = *s_pref;
-        s_h[tid] = 0u;                                // blockDim == 256 bins
-        __syncthreads();
-        for (int i = tid; i < n; i += blockDim.x) {
-            const unsigned long long K = s_k[i];
-            if (shift == 56 || (K >> (shift + 8)) == (pref >> (shift + 8)))
-                atomicAdd(&s_h[(uint32_t)(K >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const uint4 q = reinterpret_cast<const uint4 *>(s_h)[lane];
-            const uint32_t t = q.x + q.y + q.z + q.w;
-            const uint32_t suf = suffix_scan64(t, lane);
-            uint32_t digit, above, nd;
-            find_kth_bin(q, suf, t, lane, *s_rem, digit, above, nd);
-            if (lane == 0) { *s_pref = pref | ((unsigned long long)digit << shift); *s_rem -= above; }
-        }
-        __syncthreads();
-    }
-    return *s_pref;
-}
-
-template <int DECODE>
+// Finalize: one workgroup per (image, class).  The staged keys live in registers (KPT per thread).
+//   1. exact cut: the take-th largest key by an interval-narrowing radix search (256 buckets over
+//      the current [lo,hi] key interval per round, LDS histogram); keys are distinct, so the search
+//      ends as soon as the chosen bucket holds one key -- typically after two rounds;
+//   2. anchor order: selected anchors set bits of a P-bit LDS bitmap; a popcount scan gives every
+//      selected anchor its rank, i.e. its output row inside the class segment;
+//   3. decode and write.
+template <int DECODE, int KPT>
 __global__ __launch_bounds__(256) void select_finalize_kernel(
     SelParams sp, const SelRule *__restrict__ rules, const uint32_t *__restrict__ cnt,
     const unsigned long long *__restrict__ staging, const int32_t *__restrict__ seg_off,
@@ -648,10 +723,11 @@ __global__ __launch_bounds__(256) void select_finalize_kernel(
     float4 *__restrict__ out_boxes, float *__restrict__ out_scores, int64_t *__restrict__ out_cls) {
     extern __shared__ unsigned long long s_dyn64[];
     __shared__ uint32_t s_h[256];
-    __shared__ unsigned long long s_pref;
-    __shared__ uint32_t s_rem;
+    __shared__ unsigned long long s_lo, s_hi, s_cut;
+    __shared__ uint32_t s_rem, s_state;
     __shared__ uint32_t s_wsum[4];
     const int ci = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const size_t bc = (size_t)b * sp.Cs + ci;
     const int n_sel = (int)rules[bc].n_sel;
     if (n_sel == 0) return;
@@ -660,7 +736,6 @@ __global__ __launch_bounds__(256) void select_finalize_kernel(
     const int take = min(n_sel, n_stage);
     const unsigned long long *st = staging + bc * sp.cap;
     const size_t row0 = (size_t)b * ((size_t)sp.Cs * sp.top_k) + (size_t)seg_off[(size_t)b * (sp.Cs + 1) + ci];
-    unsigned long long *s_k = s_dyn64;                                  // [cap]
 
     auto emit = [&](int rank, unsigned long long K) {
         const uint32_t p = 0xffffffffu - (uint32_t)(K & 0xffffffffull);
@@ -672,20 +747,68 @@ __global__ __launch_bounds__(256) void select_finalize_kernel(
     };
 
     if (use_bitmap) {
-        for (int i = tid; i < n_stage; i += blockDim.x) s_k[i] = st[i];
-        __syncthreads();
+        unsigned long long k[KPT];                    // 0 marks an empty slot: every real key is >= 2^32
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int i = tid + j * 256;
+            k[j] = i < n_stage ? st[i] : 0ull;
+        }
         unsigned long long cutoff = 0ull;
-        if (n_stage > take) cutoff = radix_kth_largest(s_k, n_stage, (uint32_t)take, s_h, &s_pref, &s_rem);
-        // anchor order through a P-bit bitmap: rank = number of selected anchors below mine
+        if (n_stage > take) {                          // block-uniform
+            if (tid == 0) { s_lo = ~0ull; s_hi = 0ull; s_rem = (uint32_t)take; s_state = 0u; }
+            __syncthreads();
+            unsigned long long mn = ~0ull, mx = 0ull;
+#pragma unroll
+            for (int j = 0; j < KPT; ++j)
+                if (k[j]) { mn = k[j] < mn ? k[j] : mn; mx = k[j] > mx ? k[j] : mx; }
+            if (mx) { atomicMin(&s_lo, mn); atomicMax(&s_hi, mx); }
+            __syncthreads();
+            for (int round = 0; round < 12; ++round) {
+                const unsigned long long lo = s_lo, hi = s_hi;
+                const unsigned long long span = hi - lo;
+                const int sb = span ? 64 - __clzll((long long)span) : 0;
+                const int sh = sb > 8 ? sb - 8 : 0;
+                s_h[tid] = 0u;
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < KPT; ++j)
+                    if (k[j] >= lo && k[j] <= hi && k[j]) atomicAdd(&s_h[(uint32_t)((k[j] - lo) >> sh)], 1u);
+                __syncthreads();
+                if (wave == 0) {
+                    const uint4 q = reinterpret_cast<const uint4 *>(s_h)[lane];
+                    const uint32_t t = q.x + q.y + q.z + q.w;
+                    const uint32_t suf = suffix_scan64(t, lane);
+                    uint32_t digit, above, nd;
+                    find_kth_bin(q, suf, t, lane, s_rem, digit, above, nd);
+                    if (lane == 0) {
+                        const unsigned long long nlo = lo + ((unsigned long long)digit << sh);
+                        unsigned long long nhi = nlo + ((1ull << sh) - 1ull);
+                        if (nhi > hi || nhi < nlo) nhi = hi;
+                        s_lo = nlo; s_hi = nhi; s_rem -= above;
+                        s_state = (nd == 1u || nlo == nhi) ? 1u : 0u;   // one key left in [nlo, nhi]: it is the cut
+                    }
+                }
+                __syncthreads();
+                if (s_state) break;
+            }
+            {
+                const unsigned long long lo = s_lo, hi = s_hi;
+#pragma unroll
+                for (int j = 0; j < KPT; ++j)
+                    if (k[j] >= lo && k[j] <= hi && k[j]) s_cut = k[j];
+            }
+            __syncthreads();
+            cutoff = s_cut;
+        }
         const int words = (sp.P + 63) >> 6;
-        unsigned long long *s_bm = s_k + sp.cap;                        // [words]
+        unsigned long long *s_bm = s_dyn64;                             // [words]
         uint32_t *s_wp = reinterpret_cast<uint32_t *>(s_bm + words);    // [words] exclusive popcount prefix
-        for (int w = tid; w < words; w += blockDim.x) s_bm[w] = 0ull;
+        for (int w = tid; w < words; w += 256) s_bm[w] = 0ull;
         __syncthreads();
-        for (int i = tid; i < n_stage; i += blockDim.x) {
-            const unsigned long long K = s_k[i];
-            if (K >= cutoff) {
-                const uint32_t p = 0xffffffffu - (uint32_t)(K & 0xffffffffull);
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            if (k[j] && k[j] >= cutoff) {
+                const uint32_t p = 0xffffffffu - (uint32_t)(k[j] & 0xffffffffull);
                 atomicOr(&s_bm[p >> 6], 1ull << (p & 63u));
             }
         }
@@ -696,7 +819,6 @@ __global__ __launch_bounds__(256) void select_finalize_kernel(
         uint32_t local = 0;
         for (int w = w0; w < w1; ++w) local += (uint32_t)__popcll(s_bm[w]);
         uint32_t inc = local;
-        const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t up = __shfl_up(inc, o);
@@ -708,16 +830,17 @@ __global__ __launch_bounds__(256) void select_finalize_kernel(
         for (int w = 0; w < wave; ++w) base += s_wsum[w];
         for (int w = w0; w < w1; ++w) { s_wp[w] = base; base += (uint32_t)__popcll(s_bm[w]); }
         __syncthreads();
-        for (int i = tid; i < n_stage; i += blockDim.x) {
-            const unsigned long long K = s_k[i];
-            if (K >= cutoff) {
-                const uint32_t p = 0xffffffffu - (uint32_t)(K & 0xffffffffull);
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            if (k[j] && k[j] >= cutoff) {
+                const uint32_t p = 0xffffffffu - (uint32_t)(k[j] & 0xffffffffull);
                 const uint32_t rank = s_wp[p >> 6] + (uint32_t)__popcll(s_bm[p >> 6] & ((1ull << (p & 63u)) - 1ull));
-                emit((int)rank, K);
+                emit((int)rank, k[j]);
             }
         }
     } else {
         // very large P: sort the staged keys, cut, then sort the survivors by anchor index
+        unsigned long long *s_k = s_dyn64;                              // [cap]
         const int n2 = pow2_at_least(n_stage);
         for (int i = tid; i < n2; i += blockDim.x) s_k[i] = i < n_stage ? st[i] : 0ull;
         __syncthreads();
@@ -757,6 +880,7 @@ SamplePlan make_plan(int64_t P, int top_k) {
     if (P < 4096) {
         int slack = top_k / 2 > 256 ? top_k / 2 : 256;
         sp.use_sample = 0; sp.rate = 1; sp.m = 0; sp.cap = pow2_ge(top_k + slack);
+        if (sp.cap < 512) sp.cap = 512;
         return sp;
     }
     int rate = P >= 65536 ? 16 : (P >= 16384 ? 8 : 4);
@@ -768,6 +892,7 @@ SamplePlan make_plan(int64_t P, int top_k) {
         const int cap = pow2_ge((long long)(1.25 * upper) + 64);
         if (cap <= 8192 || rate <= 2) {
             sp.use_sample = 1; sp.rate = rate; sp.m = m; sp.cap = cap < 8192 ? cap : 8192;
+            if (sp.cap < 512) sp.cap = 512;
             return sp;
         }
         rate /= 2;
@@ -792,7 +917,11 @@ SelLayout layout(int64_t B, int64_t P, int64_t C, int64_t Cs, int cap, int act) 
     return L;
 }
 
-int tile_floats_for(int64_t C) { return (int)(((SUB_ROWS * C + 6) / 4 + 1) * 4); }
+int ept_for(int64_t C) { return C <= 32 ? 8 : (C <= 96 ? 24 : (C <= 128 ? 32 : 64)); }
+
+// LDS floats of one sub-tile: the data, the alignment shift, and 4*EPT floats of slack so that the
+// unconditional register loads of compute_subtile stay inside the buffer.
+int tile_floats_for(int64_t C) { return (int)(((SUB_ROWS * C + 4 * ept_for(C) + 8) / 4 + 1) * 4); }
 
 template <typename K>
 int set_lds(K kernel, size_t lds) {
@@ -801,44 +930,100 @@ int set_lds(K kernel, size_t lds) {
     return DETBOX_OK;
 }
 
-template <int ACT>
-int launch_fast(const float *in, const float *extra, const SelParams &sp, int64_t B, uint32_t *shist, SelRule *rules,
-                uint32_t *flag, uint32_t *cnt, unsigned long long *staging, float *scores_ws, hipStream_t s) {
-    const size_t tile_bytes = (size_t)sp.tile_floats * 4;
-    if (sp.use_sample) {
-        const int64_t n_sampled = (sp.n_sub + sp.sample_rate - 1) / sp.sample_rate;
-        const size_t lds = tile_bytes + (size_t)sp.Cs * (NB / 2) * 4;
-        if (int rc = set_lds(select_sample_kernel<ACT>, lds)) return rc;
-        ProfScope ps("select_sample", s);
-        select_sample_kernel<ACT><<<dim3((unsigned)((n_sampled + SAMPLE_SUBS - 1) / SAMPLE_SUBS), (unsigned)B),
-                                    dim3(SCAN_BLOCK), lds, s>>>(in, extra, sp, shist);
-        DETBOX_LAUNCH_CHECK();
-    }
-    {
-        ProfScope ps("select_plan", s);
-        select_plan_kernel<<<dim3((unsigned)B), dim3(256), 0, s>>>(shist, sp, rules, flag);
-        DETBOX_LAUNCH_CHECK();
-    }
-    const unsigned gx = (unsigned)((sp.n_sub + sp.subs_per_block - 1) / sp.subs_per_block);
-    if (sp.use_sample) {
-        const size_t lds = tile_bytes + (size_t)LCAP * 12 + (size_t)MAX_SEL_CLASSES * 12 + 16;
-        if (int rc = set_lds(select_scan_kernel<ACT>, lds)) return rc;
-        {
-            ProfScope ps("select_scan", s);
-            select_scan_kernel<ACT><<<dim3(gx, (unsigned)B), dim3(SCAN_BLOCK), lds, s>>>(in, extra, sp, rules, cnt, staging);
+struct FastArgs {
+    const float *in, *extra;
+    SelParams sp;
+    int64_t B;
+    uint32_t *shist, *flag, *cnt;
+    SelRule *rules;
+    unsigned long long *staging;
+    float *scores_ws;
+    hipStream_t s;
+};
+
+template <int ACT, int EPT>
+struct LaunchFast {
+    static int run(const FastArgs &a) {
+        const SelParams &sp = a.sp;
+        hipStream_t s = a.s;
+        const size_t tile_bytes = (size_t)sp.tile_floats * 4;
+        if (sp.use_sample) {
+            const int64_t n_sampled = (sp.n_sub + sp.sample_rate - 1) / sp.sample_rate;
+            const size_t lds = 2 * tile_bytes + (size_t)sp.Cs * (NB / 4) * 4;
+            if (int rc = set_lds(select_sample_kernel<ACT, EPT>, lds)) return rc;
+            ProfScope ps("select_sample", s);
+            select_sample_kernel<ACT, EPT><<<dim3((unsigned)((n_sampled + SAMPLE_SUBS - 1) / SAMPLE_SUBS), (unsigned)a.B),
+                                             dim3(SCAN_BLOCK), lds, s>>>(a.in, a.extra, sp, a.shist);
             DETBOX_LAUNCH_CHECK();
         }
-        ProfScope ps("select_check", s);
-        select_check_kernel<<<dim3((unsigned)B), dim3(128), 0, s>>>(sp, rules, cnt, flag);
-        DETBOX_LAUNCH_CHECK();
+        {
+            ProfScope ps("select_plan", s);
+            select_plan_kernel<<<dim3((unsigned)((sp.Cs + 3) / 4), (unsigned)a.B), dim3(256), 0, s>>>(a.shist, sp, a.rules, a.flag);
+            DETBOX_LAUNCH_CHECK();
+        }
+        const unsigned gx = (unsigned)((sp.n_sub + sp.subs_per_block - 1) / sp.subs_per_block);
+        if (sp.use_sample) {
+            const size_t lds = 2 * tile_bytes + (size_t)LCAP * 12 + (size_t)MAX_SEL_CLASSES * 8 + 16;
+            if (int rc = set_lds(select_scan_kernel<ACT, EPT>, lds)) return rc;
+            {
+                ProfScope ps("select_scan", s);
+                select_scan_kernel<ACT, EPT><<<dim3(gx, (unsigned)a.B), dim3(SCAN_BLOCK), lds, s>>>(
+                    a.in, a.extra, sp, a.rules, a.cnt, a.staging);
+                DETBOX_LAUNCH_CHECK();
+            }
+            ProfScope ps("select_check", s);
+            select_check_kernel<<<dim3((unsigned)a.B), dim3(128), 0, s>>>(sp, a.rules, a.cnt, a.flag);
+            DETBOX_LAUNCH_CHECK();
+        }
+        if (ACT != ACT_NONE) {
+            if (int rc = set_lds(activate_scores_kernel<ACT, EPT>, 2 * tile_bytes)) return rc;
+            ProfScope ps("select_materialize", s);
+            activate_scores_kernel<ACT, EPT><<<dim3(gx, (unsigned)a.B), dim3(SCAN_BLOCK), 2 * tile_bytes, s>>>(
+                a.in, a.extra, sp, a.flag, a.scores_ws);
+            DETBOX_LAUNCH_CHECK();
+        }
+        return DETBOX_OK;
     }
-    if (ACT != ACT_NONE) {
-        if (int rc = set_lds(activate_scores_kernel<ACT>, tile_bytes)) return rc;
-        ProfScope ps("select_materialize", s);
-        activate_scores_kernel<ACT><<<dim3(gx, (unsigned)B), dim3(SCAN_BLOCK), tile_bytes, s>>>(in, extra, sp, flag, scores_ws);
+};
+
+struct ActArgs {
+    const float *in, *extra;
+    SelParams sp;
+    int64_t B;
+    float *out;
+    hipStream_t s;
+};
+
+template <int ACT, int EPT>
+struct LaunchActivate {
+    static int run(const ActArgs &a) {
+        const size_t lds = 2 * (size_t)a.sp.tile_floats * 4;
+        const unsigned gx = (unsigned)((a.sp.n_sub + a.sp.subs_per_block - 1) / a.sp.subs_per_block);
+        if (int rc = set_lds(activate_scores_kernel<ACT, EPT>, lds)) return rc;
+        ProfScope ps("activate_scores", a.s);
+        activate_scores_kernel<ACT, EPT><<<dim3(gx, (unsigned)a.B), dim3(SCAN_BLOCK), lds, a.s>>>(a.in, a.extra, a.sp,
+                                                                                                  nullptr, a.out);
         DETBOX_LAUNCH_CHECK();
+        return DETBOX_OK;
     }
-    return DETBOX_OK;
+};
+
+template <template <int, int> class L, typename A>
+int dispatch_act_ept(int act, int ept, const A &a) {
+#define DETBOX_ROW(ACT)                                        \
+    switch (ept) {                                             \
+        case 8: return L<ACT, 8>::run(a);                      \
+        case 24: return L<ACT, 24>::run(a);                    \
+        case 32: return L<ACT, 32>::run(a);                    \
+        default: return L<ACT, 64>::run(a);                    \
+    }
+    switch (act) {
+        case ACT_NONE: DETBOX_ROW(ACT_NONE)
+        case ACT_SOFTMAX: DETBOX_ROW(ACT_SOFTMAX)
+        case ACT_SOFTMAX_SIGMOID: DETBOX_ROW(ACT_SOFTMAX_SIGMOID)
+        default: DETBOX_ROW(ACT_SIGMOID_SIGMOID)
+    }
+#undef DETBOX_ROW
 }
 
 int check_act(int activation, const float *extra) {
@@ -856,35 +1041,20 @@ extern "C" int detbox_activate_scores(int activation, const float *in, const flo
     if (B == 0 || P == 0) return DETBOX_OK;
     DETBOX_CHECK_ARG(in && out, "null pointer");
     DETBOX_CHECK_ARG((uintptr_t)in % 16 == 0, "input must be 16-byte aligned");
-    if (C > 4 * MAX_SEL_CLASSES) {
-        set_error("detbox_activate_scores: C = %lld beyond the limit %d", (long long)C, 4 * MAX_SEL_CLASSES);
+    if (C > 2 * MAX_SEL_CLASSES) {
+        set_error("detbox_activate_scores: C = %lld beyond the limit %d", (long long)C, 2 * MAX_SEL_CLASSES);
         return DETBOX_ERR_UNSUPPORTED;
     }
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    SelParams sp;
-    std::memset(&sp, 0, sizeof(sp));
-    sp.P = (int)P; sp.C = (int)C;
-    sp.n_sub = (int)((P + SUB_ROWS - 1) / SUB_ROWS);
-    sp.tile_floats = tile_floats_for(C);
-    int64_t spb = (B * sp.n_sub + 4095) / 4096;
-    sp.subs_per_block = (int)(spb < 1 ? 1 : spb);
-    const unsigned gx = (unsigned)((sp.n_sub + sp.subs_per_block - 1) / sp.subs_per_block);
-    const size_t lds = (size_t)sp.tile_floats * 4;
-    ProfScope ps("activate_scores", s);
-    switch (activation) {
-#define DETBOX_ACT_CASE(A)                                                                                      \
-    case A:                                                                                                     \
-        if (int rc = set_lds(activate_scores_kernel<A>, lds)) return rc;                                        \
-        activate_scores_kernel<A><<<dim3(gx, (unsigned)B), dim3(SCAN_BLOCK), lds, s>>>(in, extra, sp, nullptr, out); \
-        break;
-        DETBOX_ACT_CASE(ACT_NONE)
-        DETBOX_ACT_CASE(ACT_SOFTMAX)
-        DETBOX_ACT_CASE(ACT_SOFTMAX_SIGMOID)
-        DETBOX_ACT_CASE(ACT_SIGMOID_SIGMOID)
-#undef DETBOX_ACT_CASE
-    }
-    DETBOX_LAUNCH_CHECK();
-    return DETBOX_OK;
+    ActArgs a;
+    a.in = in; a.extra = extra; a.B = B; a.out = out; a.s = static_cast<hipStream_t>(stream);
+    std::memset(&a.sp, 0, sizeof(a.sp));
+    a.sp.P = (int)P; a.sp.C = (int)C;
+    a.sp.n_sub = (int)((P + SUB_ROWS - 1) / SUB_ROWS);
+    a.sp.tile_floats = tile_floats_for(C);
+    a.sp.total_floats = (long long)B * P * C;
+    int64_t spb = (B * a.sp.n_sub + 4095) / 4096;
+    a.sp.subs_per_block = (int)(spb < 1 ? 1 : spb);
+    return dispatch_act_ept<LaunchActivate>(activation, ept_for(C), a);
 }
 
 extern "C" size_t detbox_select_decode_workspace_bytes(int64_t B, int64_t P, int64_t C, int class_begin, int top_k,
@@ -970,18 +1140,17 @@ extern "C" int detbox_select_decode(int decode_mode, int activation, const float
     sp.use_sample = plan.use_sample; sp.sample_rate = plan.rate; sp.sample_m = plan.m;
     sp.n_sub = (int)((P + SUB_ROWS - 1) / SUB_ROWS);
     sp.tile_floats = tile_floats_for(C);
-    int64_t spb = (B * sp.n_sub + 4095) / 4096;
+    sp.total_floats = (long long)B * P * C;
+    int64_t spb = (B * sp.n_sub + 1023) / 1024;          // about two rounds of two resident workgroups per CU
     sp.subs_per_block = (int)(spb < 1 ? 1 : spb);
 
     DETBOX_HIP(hipMemsetAsync(ws, 0, L.zero_bytes, s));
-    int rc = DETBOX_OK;
-    switch (activation) {
-        case ACT_NONE: rc = launch_fast<ACT_NONE>(scores, extra, sp, B, shist, rules, flag, cnt, staging, scores_ws, s); break;
-        case ACT_SOFTMAX: rc = launch_fast<ACT_SOFTMAX>(scores, extra, sp, B, shist, rules, flag, cnt, staging, scores_ws, s); break;
-        case ACT_SOFTMAX_SIGMOID: rc = launch_fast<ACT_SOFTMAX_SIGMOID>(scores, extra, sp, B, shist, rules, flag, cnt, staging, scores_ws, s); break;
-        default: rc = launch_fast<ACT_SIGMOID_SIGMOID>(scores, extra, sp, B, shist, rules, flag, cnt, staging, scores_ws, s); break;
+    {
+        FastArgs a;
+        a.in = scores; a.extra = extra; a.sp = sp; a.B = B; a.shist = shist; a.flag = flag; a.cnt = cnt;
+        a.rules = rules; a.staging = staging; a.scores_ws = scores_ws; a.s = s;
+        if (int rc = dispatch_act_ept<LaunchFast>(activation, ept_for(C), a)) return rc;
     }
-    if (rc) return rc;
     {
         ProfScope ps("score_hist", s);
         const size_t lds = (size_t)Cs * (NB / 2) * 4 + (size_t)Cs * 4;
@@ -1009,19 +1178,28 @@ extern "C" int detbox_select_decode(int decode_mode, int activation, const float
         dim3 grid((unsigned)Cs, (unsigned)B);
         const int words = (int)((P + 63) / 64);
         const int use_bitmap = words <= BITMAP_MAX_WORDS ? 1 : 0;
-        const size_t lds = (size_t)cap * 8 + (use_bitmap ? (size_t)words * 12 + 16 : 0);
+        const size_t lds = use_bitmap ? (size_t)words * 12 + 16 : (size_t)cap * 8;
         const float4 *l4 = reinterpret_cast<const float4 *>(locs);
         float4 *ob = reinterpret_cast<float4 *>(out_boxes);
-#define DETBOX_FIN_CASE(D)                                                                                       \
-    {                                                                                                            \
-        if (int rc2 = set_lds(select_finalize_kernel<D>, lds)) return rc2;                                       \
-        select_finalize_kernel<D><<<grid, dim3(256), lds, s>>>(sp, rules, cnt, staging, out_seg_offsets, l4, anchors, \
-                                                               class_id_offset, use_bitmap, ob, out_scores, out_class_ids); \
+#define DETBOX_FIN(D, K)                                                                                          \
+    {                                                                                                             \
+        if (int rc2 = set_lds(select_finalize_kernel<D, K>, lds)) return rc2;                                     \
+        select_finalize_kernel<D, K><<<grid, dim3(256), lds, s>>>(sp, rules, cnt, staging, out_seg_offsets, l4, anchors, \
+                                                                  class_id_offset, use_bitmap, ob, out_scores, out_class_ids); \
     }
-        if (decode_mode == DETBOX_DECODE_CXCYWH) DETBOX_FIN_CASE(DETBOX_DECODE_CXCYWH)
-        else if (decode_mode == DETBOX_DECODE_YOLO) DETBOX_FIN_CASE(DETBOX_DECODE_YOLO)
-        else DETBOX_FIN_CASE(DETBOX_DECODE_FCOS)
-#undef DETBOX_FIN_CASE
+#define DETBOX_FIN_K(D)                                    \
+    switch (cap / 256) {                                   \
+        case 2: DETBOX_FIN(D, 2) break;                    \
+        case 4: DETBOX_FIN(D, 4) break;                    \
+        case 8: DETBOX_FIN(D, 8) break;                    \
+        case 16: DETBOX_FIN(D, 16) break;                  \
+        default: DETBOX_FIN(D, 32) break;                  \
+    }
+        if (decode_mode == DETBOX_DECODE_CXCYWH) { DETBOX_FIN_K(DETBOX_DECODE_CXCYWH) }
+        else if (decode_mode == DETBOX_DECODE_YOLO) { DETBOX_FIN_K(DETBOX_DECODE_YOLO) }
+        else { DETBOX_FIN_K(DETBOX_DECODE_FCOS) }
+#undef DETBOX_FIN_K
+#undef DETBOX_FIN
         DETBOX_LAUNCH_CHECK();
     }
     return DETBOX_OK;
