@@ -211,7 +211,7 @@ def main():
 
     if rank == 0:
         names = ['assign_anchor', 'assign_fixup', 'assign_fcos', 'select_sample', 'select_plan', 'select_scan',
-                 'select_check', 'select_materialize', 'score_hist', 'select_kth', 'select_refine', 'select_emit',
+                 'select_bucket', 'select_check', 'select_materialize', 'score_hist', 'select_kth', 'select_refine', 'select_emit',
                  'select_finalize', 'nms_segments', 'nms_scan', 'nms_merge', 'pack_detections']
         kern = {}
         for nm in names:

@@ -86,6 +86,18 @@ __device__ inline unsigned long long uniform64(unsigned long long v) {
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// v_min_f32 / v_max_f32 without the NaN-quieting copies fminf/fmaxf add in front of them.
+__device__ inline float vmin_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ inline float vmax_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ inline float readlane_f(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
@@ -344,6 +356,11 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_segments_fast_kernel(
 
     unsigned rem_mask = 0u;                               // bit m: own box m is suppressed
     const int lane = tid & 63, q = tid >> 6;
+    // Division-free decision: with u = (area_i + area_j) - inter > u_min,
+    //   inter > u * k_hi  =>  fl(inter / u) > thr      and      inter < u * k_lo  =>  fl(inter / u) <= thr,
+    // k_hi / k_lo being thr widened by 2^-20 either way (the roundings of the products stay below 2^-22).
+    const float k_hi = thr * 1.000001f, k_lo = thr * 0.999999f;
+    const float u_min = thr > 0.0f ? 1e-30f / thr : __builtin_inff();
     for (int ch = 0; ch < words; ++ch) {
         const int c0 = ch << 6;
         const int cn = min(64, n - c0);
@@ -406,16 +423,20 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_segments_fast_kernel(
 #pragma unroll
                     for (int m = 0; m < JPT; ++m) {
                         if (act[m]) {                                   // wave-uniform
-                            const float w = fmaxf(fminf(ix2, bj[m].z) - fmaxf(ix1, bj[m].x), 0.0f);
-                            const float h = fmaxf(fminf(iy2, bj[m].w) - fmaxf(iy1, bj[m].y), 0.0f);
+                            // One clamp is enough: with w >= 0, a negative h makes inter <= 0, which is a "no".
+                            const float w = vmax_raw(vmin_raw(ix2, bj[m].z) - vmax_raw(ix1, bj[m].x), 0.0f);
+                            const float h = vmin_raw(iy2, bj[m].w) - vmax_raw(iy1, bj[m].y);
                             const float inter = w * h;
                             const float u = (ai + aj[m]) - inter;
-                            const float p = thr * u;
-                            const unsigned long long sane = __ballot(p > 1e-30f);
-                            unsigned long long yes = __ballot(inter > p * 1.0000005f) & sane;
-                            const unsigned long long no = __ballot(inter < p * 0.9999995f) & sane;
+                            const unsigned long long sane = __ballot(u > u_min);
+                            unsigned long long yes = __ballot(inter > u * k_hi) & sane;
+                            const unsigned long long no = __ballot(inter < u * k_lo) & sane;
                             const unsigned long long amb = act[m] & ~(yes | no);
-                            if (amb) yes |= __ballot(inter / u > thr) & amb;   // the sliver the margins leave
+                            if (amb) {                                   // the sliver the margins leave: the reference's own test
+                                const float wc = fmaxf(w, 0.0f), hc = fmaxf(h, 0.0f);
+                                const float it = wc * hc;
+                                yes |= __ballot(it / ((ai + aj[m]) - it) > thr) & amb;
+                            }
                             yes &= act[m];
                             act[m] &= ~yes;
                             hit[m] |= yes;

@@ -40,9 +40,7 @@ constexpr int MAX_SEL_CLASSES = 128;  // LDS tables are sized for this many sele
 constexpr int MAX_TILE_ANCHORS = 16384;
 constexpr int SUB_ROWS = 64;          // anchors per LDS sub-tile (4 lanes per anchor row)
 constexpr int SCAN_BLOCK = 256;
-constexpr int LCAP = 3072;            // block-local candidate list (entries)
-constexpr int LFLUSH = 2048;          // flush the list to the staging lists beyond this many entries
-constexpr int SAMPLE_SUBS = 2;        // sampled sub-tiles per block of select_sample (8-bit LDS counters: <= 3)
+constexpr int SAMPLE_SUBS = 4;        // sampled sub-tiles per workgroup of select_sample
 constexpr int BITMAP_MAX_WORDS = 4096;  // finalize orders by anchor through a P-bit LDS bitmap up to this
 
 enum { ACT_NONE = 0, ACT_SOFTMAX = 1, ACT_SOFTMAX_SIGMOID = 2, ACT_SIGMOID_SIGMOID = 3 };
@@ -61,6 +59,7 @@ struct SelRule {
 struct SelParams {
     int P, C, cb, Cs, top_k, cap, shift, tile_anchors;
     int use_sample, sample_rate, sample_m, subs_per_block, n_sub, tile_floats;
+    int ns_cap, blk_cap, scan_gx;
     long long total_floats;
     float thr;
     uint32_t key_thr;
@@ -144,14 +143,31 @@ __device__ inline void dma_issue(const SubGeom &g, float *s_buf, long long total
     }
 }
 
+// What a lane needs to recompute one score of its row from the LDS tile, bit for bit.
+struct RowCtx {
+    const float *row;   // &tile[row][sub]; element i sits at row[4*i]
+    float m, inv, sg;   // soft-max maximum, 1/sum, sigmoid of the extra input
+};
+
+template <int ACT>
+__device__ inline float rescore(const RowCtx &c, int i) {
+    const float v = c.row[4 * i];
+    if (ACT == ACT_SOFTMAX) return __expf(v - c.m) * c.inv;
+    if (ACT == ACT_SOFTMAX_SIGMOID) return (__expf(v - c.m) * c.inv) * c.sg;
+    if (ACT == ACT_SIGMOID_SIGMOID) return sigmoidf_(v) * c.sg;
+    return v;
+}
+
 // Scores of this lane's elements of the sub-tile sitting in LDS: x[i] = score of class sub + 4*i of
 // local row threadIdx.x / 4 (meaningless for classes >= C).  Returns false for lanes beyond `rows`.
 template <int ACT, int EPT>
 __device__ inline bool subtile_scores(const float *s_tile, const float *__restrict__ extra, long long row_base,
-                                      int rows, int C, int shift, float (&x)[EPT]) {
+                                      int rows, int C, int shift, float (&x)[EPT], RowCtx &ctx) {
     const int r = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    ctx.row = s_tile; ctx.m = 0.f; ctx.inv = 1.f; ctx.sg = 1.f;
     if (r >= rows) return false;
     const float *row = s_tile + shift + r * C + sub;     // the tile has 4*EPT floats of slack behind it
+    ctx.row = row;
     const float fill = (ACT == ACT_SOFTMAX || ACT == ACT_SOFTMAX_SIGMOID) ? -__builtin_inff() : 0.f;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
@@ -171,8 +187,10 @@ __device__ inline bool subtile_scores(const float *s_tile, const float *__restri
         }
         sum = quad_sum(sum);
         const float inv = 1.0f / sum;
+        ctx.m = m; ctx.inv = inv;
         if (ACT == ACT_SOFTMAX_SIGMOID) {
             const float sg = sigmoidf_(extra[row_base + r]);
+            ctx.sg = sg;
 #pragma unroll
             for (int i = 0; i < EPT; ++i) x[i] = (x[i] * inv) * sg;
         } else {
@@ -181,13 +199,14 @@ __device__ inline bool subtile_scores(const float *s_tile, const float *__restri
         }
     } else if (ACT == ACT_SIGMOID_SIGMOID) {
         const float so = sigmoidf_(extra[row_base + r]);
+        ctx.sg = so;
 #pragma unroll
         for (int i = 0; i < EPT; ++i) x[i] = sigmoidf_(x[i]) * so;
     }
     return true;
 }
 
-// Runs f(x, valid, first_anchor_of_subtile) over sub-tiles first, first+step, ... (< last) of image b
+// Runs f(x, valid, first_anchor_of_subtile, ctx) over sub-tiles first, first+step, ... (< last) of image b
 // with the double-buffered DMA pipeline; after(s) runs once per sub-tile behind the barrier
 // (block-uniform work such as a flush).  s_tiles holds two buffers of tile_floats floats.
 template <int ACT, int EPT, typename F, typename G>
@@ -213,9 +232,10 @@ __device__ inline void for_each_subtile(const float *__restrict__ in, const floa
         const int r0 = (int)s * SUB_ROWS;
         const int rows = min(SUB_ROWS, P - r0);
         float x[EPT];
+        RowCtx ctx;
         const bool valid = subtile_scores<ACT, EPT>(s_tiles + buf * tile_floats, extra, (long long)b * P + r0, rows, C,
-                                                    g.shift, x);
-        f(x, valid, r0);
+                                                    g.shift, x, ctx);
+        f(x, valid, r0, ctx);
         __syncthreads();          // sub-tile s consumed by every wave, DMA of the next one landed
         after(s);
         g = gn;
@@ -237,7 +257,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void activate_scores_kernel(const float
     const int C = sp.C;
     const int r = threadIdx.x >> 2, sub = threadIdx.x & 3;
     for_each_subtile<ACT, EPT>(in, extra, b, sp.P, C, sp.total_floats, sub0, sub1, 1, s_dynf, sp.tile_floats,
-                               [&](float (&x)[EPT], bool valid, int r0) {
+                               [&](float (&x)[EPT], bool valid, int r0, const RowCtx &) {
                                    if (!valid) return;
                                    float *orow = o + (size_t)(r0 + r) * C + sub;
 #pragma unroll
@@ -251,43 +271,32 @@ __global__ __launch_bounds__(SCAN_BLOCK) void activate_scores_kernel(const float
 // Fast path
 // ---------------------------------------------------------------------------------------------
 
+// Activates every sample_rate-th sub-tile and writes its scores class-major:
+// samp[(b*Cs + ci) * ns_cap + q*64 + local_row], q = ordinal of the sampled sub-tile.
 template <int ACT, int EPT>
 __global__ __launch_bounds__(SCAN_BLOCK) void select_sample_kernel(const float *__restrict__ in,
                                                                    const float *__restrict__ extra, SelParams sp,
-                                                                   uint32_t *__restrict__ shist) {
+                                                                   float *__restrict__ samp) {
     extern __shared__ float s_dynf[];
-    // [Cs][NB/4] words of four 8-bit counters: a block sees SAMPLE_SUBS*64 <= 128 rows, so no counter overflows
-    uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_dynf + 2 * sp.tile_floats);
     const int b = blockIdx.y;
-    const int words = sp.Cs * (NB / 4);
-    for (int i = threadIdx.x; i < words; i += SCAN_BLOCK) s_hist[i] = 0u;
-    __syncthreads();
-    const float thr = sp.thr;
-    const uint32_t key_thr = sp.key_thr;
-    const int shift = sp.shift, cb = sp.cb, C = sp.C;
-    const int sub = threadIdx.x & 3;
+    const int cb = sp.cb, C = sp.C;
+    const int r = threadIdx.x >> 2, sub = threadIdx.x & 3;
     const long long first = (long long)blockIdx.x * SAMPLE_SUBS * sp.sample_rate;
     const long long last = min((long long)sp.n_sub, first + (long long)SAMPLE_SUBS * sp.sample_rate);
-    for_each_subtile<ACT, EPT>(in, extra, b, sp.P, C, sp.total_floats, first, last, sp.sample_rate, s_dynf, sp.tile_floats,
-                               [&](float (&x)[EPT], bool valid, int) {
+    float *sb = samp + (size_t)b * sp.Cs * sp.ns_cap;
+    const int rate = sp.sample_rate, ns_cap = sp.ns_cap;
+    for_each_subtile<ACT, EPT>(in, extra, b, sp.P, C, sp.total_floats, first, last, rate, s_dynf, sp.tile_floats,
+                               [&](float (&x)[EPT], bool valid, int r0, const RowCtx &) {
                                    if (!valid) return;
+                                   const int q = (r0 / SUB_ROWS) / rate;
+                                   float *o = sb + (size_t)q * SUB_ROWS + r;
 #pragma unroll
                                    for (int i = 0; i < EPT; ++i) {
                                        const int c = sub + 4 * i;
-                                       if (c >= cb && c < C && x[i] > thr) {
-                                           const uint32_t bin = bin_of(okey(x[i]) - key_thr, shift);
-                                           atomicAdd(&s_hist[(c - cb) * (NB / 4) + (bin >> 2)], 1u << ((bin & 3u) * 8u));
-                                       }
+                                       if (c >= cb && c < C) o[(size_t)(c - cb) * ns_cap] = x[i];
                                    }
                                },
                                [](long long) {});
-    uint32_t *gh = shist + (size_t)b * sp.Cs * NB;
-    for (int i = threadIdx.x; i < words; i += SCAN_BLOCK) {
-        uint32_t v = s_hist[i];
-#pragma unroll
-        for (int q = 0; q < 4; ++q, v >>= 8)
-            if (v & 0xffu) atomicAdd(&gh[4 * i + q], v & 0xffu);
-    }
 }
 
 // Suffix sums of a 256-bin histogram row held four bins per lane; returns the lane's suffix sum.
@@ -319,56 +328,88 @@ __device__ inline void find_kth_bin(uint4 q, uint32_t suf, uint32_t t, int lane,
     beta = __shfl(b_, L); n_above = __shfl(a_, L); n_beta = __shfl(nb_, L);
 }
 
-__global__ __launch_bounds__(256) void select_plan_kernel(const uint32_t *__restrict__ shist, SelParams sp,
+// Per (image, class): the sample_m-th largest sampled score, found exactly by a 4-round radix search
+// on the monotone uint32 image of the scores; it becomes the staging threshold t_lo of the scan.
+// With no more than sample_m sampled scores above the threshold, everything above it is staged.
+__global__ __launch_bounds__(256) void select_plan_kernel(const float *__restrict__ samp, SelParams sp,
                                                           SelRule *__restrict__ rules, uint32_t *__restrict__ flag) {
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int ci = blockIdx.x * 4 + (threadIdx.x >> 6);          // one wave per (image, class)
-    if (!sp.use_sample && b == 0 && blockIdx.x == 0 && threadIdx.x == 0) *flag = 1u;
-    if (ci >= sp.Cs) return;
+    extern __shared__ uint32_t s_key[];              // [ns_cap] keys of the sampled scores above the threshold (0 = none)
+    __shared__ uint32_t s_h[256];
+    __shared__ uint32_t s_pref, s_rem, s_total;
+    const int ci = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     SelRule r;
     r.pad = 0; r.cutoff = 0ull; r.n_above = 0; r.n_sel = 0;
     if (!sp.use_sample) {
+        if (b == 0 && ci == 0 && tid == 0) *flag = 1u;
         r.mode = RULE_PENDING; r.beta = 0; r.min_score = __builtin_inff();
-    } else {
-        const uint32_t *h = shist + ((size_t)b * sp.Cs + ci) * NB;
-        const uint4 q = reinterpret_cast<const uint4 *>(h)[lane];
-        const uint32_t t = q.x + q.y + q.z + q.w;
-        const uint32_t suf = suffix_scan64(t, lane);
-        const uint32_t total = __shfl(suf, 0);
-        r.mode = RULE_STAGED;
-        unsigned long long dmin = 1ull;
-        if (total > (uint32_t)sp.sample_m) {
-            uint32_t beta, n_above, n_beta;
-            find_kth_bin(q, suf, t, lane, (uint32_t)sp.sample_m, beta, n_above, n_beta);
-            dmin = (unsigned long long)beta << sp.shift;
-            if (dmin < 1ull) dmin = 1ull;
-        }
-        r.beta = dmin == 1ull ? 1u : 0u;            // 1: everything above the threshold gets staged
-        r.min_score = score_from_d(sp.key_thr, dmin);
+        if (tid == 0) rules[(size_t)b * sp.Cs + ci] = r;
+        return;
     }
-    if (lane == 0) rules[(size_t)b * sp.Cs + ci] = r;
+    if (tid == 0) { s_total = 0u; s_pref = 0u; s_rem = (uint32_t)sp.sample_m; }
+    __syncthreads();
+    const float *sv = samp + ((size_t)b * sp.Cs + ci) * sp.ns_cap;
+    uint32_t mine = 0;
+    for (int i = tid; i < sp.ns_cap; i += 256) {
+        const long long row = (long long)(i / SUB_ROWS) * sp.sample_rate * SUB_ROWS + (i % SUB_ROWS);
+        uint32_t k = 0u;
+        if (row < sp.P) {
+            const float v = sv[i];
+            if (v > sp.thr) { k = okey(v) - sp.key_thr; ++mine; }     // k >= 1
+        }
+        s_key[i] = k;
+    }
+    if (mine) atomicAdd(&s_total, mine);
+    __syncthreads();
+    r.mode = RULE_STAGED;
+    unsigned long long dmin = 1ull;
+    if (s_total > (uint32_t)sp.sample_m) {              // block-uniform
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            const uint32_t pref = s_pref;
+            s_h[tid] = 0u;
+            __syncthreads();
+            for (int i = tid; i < sp.ns_cap; i += 256) {
+                const uint32_t k = s_key[i];
+                if (k && (shift == 24 || (k >> (shift + 8)) == (pref >> (shift + 8)))) atomicAdd(&s_h[(k >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const uint4 q = reinterpret_cast<const uint4 *>(s_h)[lane];
+                const uint32_t t = q.x + q.y + q.z + q.w;
+                const uint32_t suf = suffix_scan64(t, lane);
+                uint32_t digit, above, nd;
+                find_kth_bin(q, suf, t, lane, s_rem, digit, above, nd);
+                if (lane == 0) { s_pref = pref | (digit << shift); s_rem -= above; }
+            }
+            __syncthreads();
+        }
+        dmin = s_pref;
+    }
+    r.beta = dmin == 1ull ? 1u : 0u;            // 1: everything above the threshold gets staged
+    r.min_score = score_from_d(sp.key_thr, dmin);
+    if (tid == 0) rules[(size_t)b * sp.Cs + ci] = r;
+}
+
+// Staged candidate as the scan writes it: score key (32) | class slot (8) | anchor (24).
+__device__ inline unsigned long long pack_entry(uint32_t d, uint32_t ci, uint32_t p) {
+    return ((unsigned long long)d << 32) | ((unsigned long long)ci << 24) | (unsigned long long)p;
 }
 
 template <int ACT, int EPT>
 __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__restrict__ in,
                                                                  const float *__restrict__ extra, SelParams sp,
                                                                  const SelRule *__restrict__ rules,
-                                                                 uint32_t *__restrict__ gcnt,
-                                                                 unsigned long long *__restrict__ staging) {
+                                                                 uint32_t *__restrict__ blk_cnt,
+                                                                 unsigned long long *__restrict__ blk_list,
+                                                                 uint32_t *__restrict__ img_ovf) {
     extern __shared__ float s_dynf[];
-    unsigned long long *s_lk = reinterpret_cast<unsigned long long *>(s_dynf + 2 * sp.tile_floats);   // [LCAP]
-    uint32_t *s_lmeta = reinterpret_cast<uint32_t *>(s_lk + LCAP);                                    // [LCAP]
-    uint32_t *s_ccount = s_lmeta + LCAP;                                                              // [MAX_SEL_CLASSES]
-    uint32_t *s_cbase = s_ccount + MAX_SEL_CLASSES;
-    uint32_t *s_n = s_cbase + MAX_SEL_CLASSES;
-
+    uint32_t *s_n = reinterpret_cast<uint32_t *>(s_dynf + 2 * sp.tile_floats);
     const int b = blockIdx.y, tid = threadIdx.x;
-    const int Cs = sp.Cs, cb = sp.cb, cap = sp.cap, C = sp.C;
+    const int Cs = sp.Cs, cb = sp.cb, C = sp.C;
     const uint32_t key_thr = sp.key_thr;
     const SelRule *rb = rules + (size_t)b * Cs;
-    uint32_t *gc = gcnt + (size_t)b * Cs;
-    unsigned long long *stg = staging + (size_t)b * Cs * cap;
+    const size_t blk = (size_t)b * gridDim.x + blockIdx.x;
+    unsigned long long *list = blk_list + blk * sp.blk_cap;
+    const uint32_t blk_cap = (uint32_t)sp.blk_cap;
     // the lane's classes never change: their staging thresholds live in registers
     const int r = tid >> 2, sub = tid & 3;
     float tlo[EPT];
@@ -384,66 +425,75 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
     const long long sub1 = min((long long)sp.n_sub, sub0 + sp.subs_per_block);
     for_each_subtile<ACT, EPT>(
         in, extra, b, sp.P, C, sp.total_floats, sub0, sub1, 1, s_dynf, sp.tile_floats,
-        [&](float (&x)[EPT], bool valid, int r0) {
+        [&](float (&x)[EPT], bool valid, int r0, const RowCtx &ctx) {
             unsigned long long pm = 0ull;               // bit i: element i is staged
             if (valid) {
 #pragma unroll
                 for (int i = 0; i < EPT; ++i) pm |= (unsigned long long)(x[i] >= tlo[i]) << i;
             }
-            if (pm) {                                   // one LDS reservation per lane with candidates
+            if (pm) {                                   // rare: one reservation per lane, then its few candidates
                 uint32_t slot = atomicAdd(s_n, (uint32_t)__popcll(pm));
                 const uint32_t p = (uint32_t)(r0 + r);
-#pragma unroll
-                for (int i = 0; i < EPT; ++i) {
-                    if ((pm >> i) & 1ull) {
-                        const int ci = sub + 4 * i - cb;
-                        const unsigned long long K = make_key(x[i], key_thr, p);
-                        if (slot < (uint32_t)LCAP) {
-                            s_lk[slot] = K;
-                            s_lmeta[slot] = (uint32_t)ci;
-                        } else {                          // block list full: straight to the staging list
-                            const uint32_t g = atomicAdd(&gc[ci], 1u);
-                            if (g < (uint32_t)cap) stg[(size_t)ci * cap + g] = K;
-                        }
-                        ++slot;
-                    }
-                }
+                do {
+                    const int i = __ffsll((long long)pm) - 1;
+                    pm &= pm - 1ull;
+                    const float sc = rescore<ACT>(ctx, i);           // same arithmetic as x[i], bit for bit
+                    if (slot < blk_cap) list[slot] = pack_entry(okey(sc) - key_thr, (uint32_t)(sub + 4 * i - cb), p);
+                    ++slot;
+                } while (pm);
             }
         },
-        [&](long long s) {
-            const uint32_t n_raw = *s_n;                  // block-uniform: read behind a barrier
-            if (n_raw > (uint32_t)LFLUSH || s == sub1 - 1) {
-                const int n = (int)min(n_raw, (uint32_t)LCAP);
-                if (tid < MAX_SEL_CLASSES) s_ccount[tid] = 0u;
-                __syncthreads();
-                for (int e = tid; e < n; e += SCAN_BLOCK) {
-                    const uint32_t ci = s_lmeta[e];
-                    s_lmeta[e] = ci | (atomicAdd(&s_ccount[ci], 1u) << 16);
-                }
-                __syncthreads();
-                if (tid < Cs && s_ccount[tid]) s_cbase[tid] = atomicAdd(&gc[tid], s_ccount[tid]);
-                __syncthreads();
-                for (int e = tid; e < n; e += SCAN_BLOCK) {
-                    const uint32_t meta = s_lmeta[e];
-                    const uint32_t ci = meta & 0xffffu;
-                    const uint32_t pos = s_cbase[ci] + (meta >> 16);
-                    if (pos < (uint32_t)cap) stg[(size_t)ci * cap + pos] = s_lk[e];
-                }
-                __syncthreads();
-                if (tid == 0) *s_n = 0u;
-                __syncthreads();
-            }
-        });
+        [](long long) {});
+    if (tid == 0) {
+        const uint32_t n = *s_n;                          // behind the loop's last barrier
+        blk_cnt[blk] = n < blk_cap ? n : blk_cap;
+        if (n > blk_cap) img_ovf[b] = 1u;                 // the image falls back to the exact path
+    }
+}
+
+// Distributes one scan workgroup's candidate list over the per-(image,class) staging lists: counting
+// sort by class in LDS, one global atomic per class present, then the scatter.
+__global__ __launch_bounds__(256) void select_bucket_kernel(SelParams sp, const uint32_t *__restrict__ blk_cnt,
+                                                            const unsigned long long *__restrict__ blk_list,
+                                                            uint32_t *__restrict__ gcnt,
+                                                            unsigned long long *__restrict__ staging) {
+    __shared__ uint32_t s_ccount[MAX_SEL_CLASSES], s_cbase[MAX_SEL_CLASSES];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const size_t blk = (size_t)b * gridDim.x + blockIdx.x;
+    const int n = (int)blk_cnt[blk];
+    if (n == 0) return;
+    const unsigned long long *list = blk_list + blk * sp.blk_cap;
+    const int Cs = sp.Cs, cap = sp.cap;
+    if (tid < MAX_SEL_CLASSES) s_ccount[tid] = 0u;
+    __syncthreads();
+    for (int e = tid; e < n; e += 256) atomicAdd(&s_ccount[(uint32_t)(list[e] >> 24) & 0xffu], 1u);
+    __syncthreads();
+    if (tid < Cs) {
+        const uint32_t c = s_ccount[tid];
+        s_cbase[tid] = c ? atomicAdd(&gcnt[(size_t)b * Cs + tid], c) : 0u;
+        s_ccount[tid] = 0u;
+    }
+    __syncthreads();
+    unsigned long long *stg = staging + (size_t)b * Cs * cap;
+    for (int e = tid; e < n; e += 256) {
+        const unsigned long long en = list[e];
+        const uint32_t ci = (uint32_t)(en >> 24) & 0xffu;
+        const uint32_t pos = s_cbase[ci] + atomicAdd(&s_ccount[ci], 1u);
+        const uint32_t p = (uint32_t)en & 0xffffffu;
+        if (pos < (uint32_t)cap)
+            stg[(size_t)ci * cap + pos] = (en & 0xffffffff00000000ull) | (unsigned long long)(0xffffffffu - p);
+    }
 }
 
 __global__ __launch_bounds__(128) void select_check_kernel(SelParams sp, SelRule *__restrict__ rules,
-                                                           uint32_t *__restrict__ gcnt, uint32_t *__restrict__ flag) {
+                                                           uint32_t *__restrict__ gcnt, const uint32_t *__restrict__ img_ovf,
+                                                           uint32_t *__restrict__ flag) {
     const int b = blockIdx.x, ci = threadIdx.x;
     if (ci >= sp.Cs) return;
     SelRule *r = rules + (size_t)b * sp.Cs + ci;
     if (r->mode != RULE_STAGED) return;
     const uint32_t n = gcnt[(size_t)b * sp.Cs + ci];
-    const bool ok = n <= (uint32_t)sp.cap && (r->beta != 0u || n >= (uint32_t)sp.top_k);
+    const bool ok = !img_ovf[b] && n <= (uint32_t)sp.cap && (r->beta != 0u || n >= (uint32_t)sp.top_k);
     if (ok) {
         r->n_sel = n < (uint32_t)sp.top_k ? n : (uint32_t)sp.top_k;
     } else {
@@ -870,47 +920,70 @@ int pow2_ge(long long need) {
     return cap;
 }
 
-struct SamplePlan { int use_sample, rate, m, cap; };
+// Everything the host derives from the problem size: the sampling plan, the staging capacities and
+// the geometry of the scan.
+struct SelPlan {
+    int use_sample, rate, m, cap;   // cap: entries of one (image,class) staging list
+    int n_sub, ns_cap;              // sub-tiles per image; sampled rows per (image,class) (multiple of SUB_ROWS)
+    int subs_per_block, scan_gx;    // scan: sub-tiles per workgroup, workgroups per image
+    int blk_cap;                    // entries of one scan workgroup's candidate list
+};
 
-// Sampling plan.  With a 1-in-rate sample, the score whose sample rank is m has, with probability
-// about 1 - 3e-6 (z = 4.5 standard deviations of the binomial), at least top_k scores at or above it.
-SamplePlan make_plan(int64_t P, int top_k) {
-    SamplePlan sp;
+// With a 1-in-rate sample, the score whose sample rank is m has, with probability about 1 - 3e-6
+// (z = 4.5 standard deviations of the binomial), at least top_k scores at or above it; `upper` bounds
+// the number of scores at or above it by the same margin on the other side.
+SelPlan make_plan(int64_t B, int64_t P, int64_t Cs, int top_k) {
+    SelPlan sp;
+    std::memset(&sp, 0, sizeof(sp));
     const double z = 4.5;
-    if (P < 4096) {
+    sp.n_sub = (int)((P + SUB_ROWS - 1) / SUB_ROWS);
+    int64_t spb = (B * sp.n_sub + 1023) / 1024;          // about two rounds of resident workgroups
+    sp.subs_per_block = (int)(spb < 1 ? 1 : spb);
+    sp.scan_gx = (sp.n_sub + sp.subs_per_block - 1) / sp.subs_per_block;
+    if (P < 4096 || P > (1 << 24)) {                     // tiny inputs, or anchors beyond the 24-bit entry field
         int slack = top_k / 2 > 256 ? top_k / 2 : 256;
         sp.use_sample = 0; sp.rate = 1; sp.m = 0; sp.cap = pow2_ge(top_k + slack);
         if (sp.cap < 512) sp.cap = 512;
+        sp.ns_cap = SUB_ROWS; sp.blk_cap = 256;
         return sp;
     }
     int rate = P >= 65536 ? 16 : (P >= 16384 ? 8 : 4);
+    double upper = 0.0;
     for (;;) {
         const double kr = (double)top_k / rate;
         const double sq = 0.5 * (z + std::sqrt(z * z + 4.0 * kr));
         const int m = (int)std::ceil(sq * sq);
-        const double upper = (double)m * rate + z * rate * std::sqrt((double)m);
-        const int cap = pow2_ge((long long)(1.25 * upper) + 64);
+        upper = (double)m * rate + z * rate * std::sqrt((double)m);
+        const int cap = pow2_ge((long long)upper + 64);
         if (cap <= 8192 || rate <= 2) {
             sp.use_sample = 1; sp.rate = rate; sp.m = m; sp.cap = cap < 8192 ? cap : 8192;
             if (sp.cap < 512) sp.cap = 512;
-            return sp;
+            break;
         }
         rate /= 2;
     }
+    sp.ns_cap = ((sp.n_sub + sp.rate - 1) / sp.rate) * SUB_ROWS;
+    // a scan workgroup sees subs_per_block*64 of the P anchors: twice its share of the worst case, plus slack
+    const double share = (double)sp.subs_per_block * SUB_ROWS / (double)P;
+    sp.blk_cap = pow2_ge((long long)(2.0 * share * upper * (double)Cs) + 1024);
+    return sp;
 }
 
-struct SelLayout { size_t hist, shist, cnt, flag, rules, staging, scores, total, zero_bytes; };
+struct SelLayout { size_t hist, cnt, flag, img_ovf, blk_cnt, rules, staging, samp, blk_list, scores, total, zero_bytes; };
 
-SelLayout layout(int64_t B, int64_t P, int64_t C, int64_t Cs, int cap, int act) {
+SelLayout layout(int64_t B, int64_t P, int64_t C, int64_t Cs, const SelPlan &pl, int act) {
     SelLayout L;
     size_t off = 0;
     L.hist = off; off = align_up(off + (size_t)B * Cs * NB * sizeof(uint32_t), 256);
-    L.shist = off; off = align_up(off + (size_t)B * Cs * NB * sizeof(uint32_t), 256);
     L.cnt = off; off = align_up(off + (size_t)B * Cs * sizeof(uint32_t), 256);
     L.flag = off; off = align_up(off + sizeof(uint32_t), 256);
-    L.zero_bytes = off;                      // histograms, counters and the flag are cleared every call
+    L.img_ovf = off; off = align_up(off + (size_t)B * sizeof(uint32_t), 256);
+    L.blk_cnt = off; off = align_up(off + (size_t)B * pl.scan_gx * sizeof(uint32_t), 256);
+    L.zero_bytes = off;                      // histogram, counters and flags are cleared every call
     L.rules = off; off = align_up(off + (size_t)B * Cs * sizeof(SelRule), 256);
-    L.staging = off; off = align_up(off + (size_t)B * Cs * cap * sizeof(unsigned long long), 256);
+    L.staging = off; off = align_up(off + (size_t)B * Cs * pl.cap * sizeof(unsigned long long), 256);
+    L.samp = off; off = align_up(off + (size_t)B * Cs * pl.ns_cap * sizeof(float), 256);
+    L.blk_list = off; off = align_up(off + (size_t)B * pl.scan_gx * pl.blk_cap * sizeof(unsigned long long), 256);
     L.scores = off;
     if (act != ACT_NONE) off = align_up(off + (size_t)B * P * C * sizeof(float), 256);   // fallback only
     L.total = off;
@@ -934,10 +1007,10 @@ struct FastArgs {
     const float *in, *extra;
     SelParams sp;
     int64_t B;
-    uint32_t *shist, *flag, *cnt;
+    uint32_t *flag, *cnt, *img_ovf, *blk_cnt;
     SelRule *rules;
-    unsigned long long *staging;
-    float *scores_ws;
+    unsigned long long *staging, *blk_list;
+    float *samp, *scores_ws;
     hipStream_t s;
 };
 
@@ -949,30 +1022,36 @@ struct LaunchFast {
         const size_t tile_bytes = (size_t)sp.tile_floats * 4;
         if (sp.use_sample) {
             const int64_t n_sampled = (sp.n_sub + sp.sample_rate - 1) / sp.sample_rate;
-            const size_t lds = 2 * tile_bytes + (size_t)sp.Cs * (NB / 4) * 4;
-            if (int rc = set_lds(select_sample_kernel<ACT, EPT>, lds)) return rc;
+            if (int rc = set_lds(select_sample_kernel<ACT, EPT>, 2 * tile_bytes)) return rc;
             ProfScope ps("select_sample", s);
             select_sample_kernel<ACT, EPT><<<dim3((unsigned)((n_sampled + SAMPLE_SUBS - 1) / SAMPLE_SUBS), (unsigned)a.B),
-                                             dim3(SCAN_BLOCK), lds, s>>>(a.in, a.extra, sp, a.shist);
+                                             dim3(SCAN_BLOCK), 2 * tile_bytes, s>>>(a.in, a.extra, sp, a.samp);
             DETBOX_LAUNCH_CHECK();
         }
         {
+            const size_t lds = (size_t)sp.ns_cap * 4;
+            if (int rc = set_lds(select_plan_kernel, lds)) return rc;
             ProfScope ps("select_plan", s);
-            select_plan_kernel<<<dim3((unsigned)((sp.Cs + 3) / 4), (unsigned)a.B), dim3(256), 0, s>>>(a.shist, sp, a.rules, a.flag);
+            select_plan_kernel<<<dim3((unsigned)sp.Cs, (unsigned)a.B), dim3(256), lds, s>>>(a.samp, sp, a.rules, a.flag);
             DETBOX_LAUNCH_CHECK();
         }
-        const unsigned gx = (unsigned)((sp.n_sub + sp.subs_per_block - 1) / sp.subs_per_block);
+        const unsigned gx = (unsigned)sp.scan_gx;
         if (sp.use_sample) {
-            const size_t lds = 2 * tile_bytes + (size_t)LCAP * 12 + (size_t)MAX_SEL_CLASSES * 8 + 16;
+            const size_t lds = 2 * tile_bytes + 16;
             if (int rc = set_lds(select_scan_kernel<ACT, EPT>, lds)) return rc;
             {
                 ProfScope ps("select_scan", s);
                 select_scan_kernel<ACT, EPT><<<dim3(gx, (unsigned)a.B), dim3(SCAN_BLOCK), lds, s>>>(
-                    a.in, a.extra, sp, a.rules, a.cnt, a.staging);
+                    a.in, a.extra, sp, a.rules, a.blk_cnt, a.blk_list, a.img_ovf);
+                DETBOX_LAUNCH_CHECK();
+            }
+            {
+                ProfScope ps("select_bucket", s);
+                select_bucket_kernel<<<dim3(gx, (unsigned)a.B), dim3(256), 0, s>>>(sp, a.blk_cnt, a.blk_list, a.cnt, a.staging);
                 DETBOX_LAUNCH_CHECK();
             }
             ProfScope ps("select_check", s);
-            select_check_kernel<<<dim3((unsigned)a.B), dim3(128), 0, s>>>(sp, a.rules, a.cnt, a.flag);
+            select_check_kernel<<<dim3((unsigned)a.B), dim3(128), 0, s>>>(sp, a.rules, a.cnt, a.img_ovf, a.flag);
             DETBOX_LAUNCH_CHECK();
         }
         if (ACT != ACT_NONE) {
@@ -1052,7 +1131,7 @@ extern "C" int detbox_activate_scores(int activation, const float *in, const flo
     a.sp.n_sub = (int)((P + SUB_ROWS - 1) / SUB_ROWS);
     a.sp.tile_floats = tile_floats_for(C);
     a.sp.total_floats = (long long)B * P * C;
-    int64_t spb = (B * a.sp.n_sub + 4095) / 4096;
+    int64_t spb = (B * a.sp.n_sub + 2047) / 2048;
     a.sp.subs_per_block = (int)(spb < 1 ? 1 : spb);
     return dispatch_act_ept<LaunchActivate>(activation, ept_for(C), a);
 }
@@ -1060,7 +1139,7 @@ extern "C" int detbox_activate_scores(int activation, const float *in, const flo
 extern "C" size_t detbox_select_decode_workspace_bytes(int64_t B, int64_t P, int64_t C, int class_begin, int top_k,
                                                        int activation) {
     if (B <= 0 || C <= class_begin || top_k <= 0) return 256;
-    return layout(B, P, C, C - class_begin, make_plan(P, top_k).cap, activation).total;
+    return layout(B, P, C, C - class_begin, make_plan(B, P, C - class_begin, top_k), activation).total;
 }
 
 extern "C" int detbox_select_decode(int decode_mode, int activation, const float *scores, const float *extra,
@@ -1100,20 +1179,23 @@ extern "C" int detbox_select_decode(int decode_mode, int activation, const float
                      "scores, locs and out_boxes must be 16-byte aligned");
     DETBOX_CHECK_ARG(decode_mode != DETBOX_DECODE_CXCYWH || (uintptr_t)anchors % 16 == 0, "anchors must be 16-byte aligned");
     DETBOX_CHECK_ARG(decode_mode != DETBOX_DECODE_FCOS || (uintptr_t)anchors % 8 == 0, "points must be 8-byte aligned");
-    const SamplePlan plan = make_plan(P, top_k);
+    const SelPlan plan = make_plan(B, P, Cs, top_k);
     const int cap = plan.cap;
-    const SelLayout L = layout(B, P, C, Cs, cap, activation);
+    const SelLayout L = layout(B, P, C, Cs, plan, activation);
     if (!workspace || (uintptr_t)workspace % 256 || workspace_bytes < L.total) {
         set_error("detbox_select_decode: workspace missing, misaligned or smaller than %zu bytes", L.total);
         return DETBOX_ERR_WORKSPACE;
     }
     char *ws = static_cast<char *>(workspace);
     uint32_t *ghist = reinterpret_cast<uint32_t *>(ws + L.hist);
-    uint32_t *shist = reinterpret_cast<uint32_t *>(ws + L.shist);
     uint32_t *cnt = reinterpret_cast<uint32_t *>(ws + L.cnt);
     uint32_t *flag = reinterpret_cast<uint32_t *>(ws + L.flag);
+    uint32_t *img_ovf = reinterpret_cast<uint32_t *>(ws + L.img_ovf);
+    uint32_t *blk_cnt = reinterpret_cast<uint32_t *>(ws + L.blk_cnt);
     SelRule *rules = reinterpret_cast<SelRule *>(ws + L.rules);
     unsigned long long *staging = reinterpret_cast<unsigned long long *>(ws + L.staging);
+    float *samp = reinterpret_cast<float *>(ws + L.samp);
+    unsigned long long *blk_list = reinterpret_cast<unsigned long long *>(ws + L.blk_list);
     float *scores_ws = reinterpret_cast<float *>(ws + L.scores);
     const float *scores_eff = activation == ACT_NONE ? scores : scores_ws;
 
@@ -1138,17 +1220,17 @@ extern "C" int detbox_select_decode(int decode_mode, int activation, const float
     sp.tile_anchors = (int)tile;
     const int64_t tiles = (P + tile - 1) / tile;
     sp.use_sample = plan.use_sample; sp.sample_rate = plan.rate; sp.sample_m = plan.m;
-    sp.n_sub = (int)((P + SUB_ROWS - 1) / SUB_ROWS);
+    sp.n_sub = plan.n_sub; sp.ns_cap = plan.ns_cap; sp.blk_cap = plan.blk_cap;
+    sp.subs_per_block = plan.subs_per_block; sp.scan_gx = plan.scan_gx;
     sp.tile_floats = tile_floats_for(C);
     sp.total_floats = (long long)B * P * C;
-    int64_t spb = (B * sp.n_sub + 1023) / 1024;          // about two rounds of two resident workgroups per CU
-    sp.subs_per_block = (int)(spb < 1 ? 1 : spb);
 
     DETBOX_HIP(hipMemsetAsync(ws, 0, L.zero_bytes, s));
     {
         FastArgs a;
-        a.in = scores; a.extra = extra; a.sp = sp; a.B = B; a.shist = shist; a.flag = flag; a.cnt = cnt;
-        a.rules = rules; a.staging = staging; a.scores_ws = scores_ws; a.s = s;
+        a.in = scores; a.extra = extra; a.sp = sp; a.B = B; a.flag = flag; a.cnt = cnt; a.img_ovf = img_ovf;
+        a.blk_cnt = blk_cnt; a.rules = rules; a.staging = staging; a.blk_list = blk_list; a.samp = samp;
+        a.scores_ws = scores_ws; a.s = s;
         if (int rc = dispatch_act_ept<LaunchFast>(activation, ept_for(C), a)) return rc;
     }
     {
