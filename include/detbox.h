@@ -179,6 +179,9 @@ int detbox_pack_detections(const float *boxes, const float *scores, const int64_
  * "select_refine", "select_emit", "select_finalize", "nms_segments", "nms_scan", "nms_merge",
  * "nms_write", "pack_detections". */
 int detbox_profile_enable(int on);
+/* Restricts the timing to the one kernel called `name` (NULL or "" = every kernel again), so that a
+ * timed run pays the event overhead for that kernel only. */
+int detbox_profile_only(const char *name);
 int detbox_profile_reset(void);
 int detbox_profile_read(const char *name, double *total_ms, int64_t *launches);
 

@@ -31,6 +31,7 @@ SIGNATURES = {
     'detbox_pack_detections': (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
     'detbox_debug_stream_read': (_i32, [_p, _i64, _p, _i32, _p]),
     'detbox_profile_enable': (_i32, [_i32]),
+    'detbox_profile_only': (_i32, [ctypes.c_char_p]),
     'detbox_profile_reset': (_i32, []),
     'detbox_profile_read': (_i32, [ctypes.c_char_p, ctypes.POINTER(_f64), ctypes.POINTER(_i64)]),
 }

@@ -31,12 +31,20 @@ static std::mutex g_pmu;
 static bool g_prof_on = false;
 static std::map<std::string, std::vector<Sample>> g_samples;
 static std::map<std::string, hipEvent_t> g_open;   // begin event waiting for its end
+static std::vector<hipEvent_t> g_free;             // recycled events
+static std::string g_only;                         // if not empty: the one scope that is timed
+
+static bool take_event(hipEvent_t *ev) {
+    if (!g_free.empty()) { *ev = g_free.back(); g_free.pop_back(); return true; }
+    return hipEventCreate(ev) == hipSuccess;
+}
 
 void prof_begin(const char *name, hipStream_t s) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_pmu);
+    if (!g_only.empty() && g_only != name) return;
     hipEvent_t ev;
-    if (hipEventCreate(&ev) != hipSuccess) return;
+    if (!take_event(&ev)) return;
     (void)hipEventRecord(ev, s);
     g_open[name] = ev;
 }
@@ -47,7 +55,7 @@ void prof_end(const char *name, hipStream_t s) {
     auto it = g_open.find(name);
     if (it == g_open.end()) return;
     hipEvent_t ev;
-    if (hipEventCreate(&ev) != hipSuccess) return;
+    if (!take_event(&ev)) return;
     (void)hipEventRecord(ev, s);
     g_samples[name].push_back({it->second, ev});
     g_open.erase(it);
@@ -69,12 +77,18 @@ int detbox_profile_enable(int on) {
     return DETBOX_OK;
 }
 
+int detbox_profile_only(const char *name) {
+    std::lock_guard<std::mutex> lk(g_pmu);
+    g_only = name ? name : "";
+    return DETBOX_OK;
+}
+
 int detbox_profile_reset(void) {
     std::lock_guard<std::mutex> lk(g_pmu);
     for (auto &kv : g_samples)
-        for (auto &s : kv.second) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+        for (auto &s : kv.second) { g_free.push_back(s.a); g_free.push_back(s.b); }
     g_samples.clear();
-    for (auto &kv : g_open) (void)hipEventDestroy(kv.second);
+    for (auto &kv : g_open) g_free.push_back(kv.second);
     g_open.clear();
     return DETBOX_OK;
 }

@@ -266,6 +266,11 @@ def profile_enable(on: bool = True):
     _lib.check(_lib.lib().detbox_profile_enable(int(on)), 'detbox_profile_enable')
 
 
+def profile_only(name: str = ''):
+    """Time only the kernel called `name` ('' = all kernels)."""
+    _lib.check(_lib.lib().detbox_profile_only(name.encode()), 'detbox_profile_only')
+
+
 def profile_reset():
     _lib.check(_lib.lib().detbox_profile_reset(), 'detbox_profile_reset')
 
