@@ -22,8 +22,6 @@
 #include "detbox_internal.h"
 
 #include <cmath>
-#include <cstdlib>
-#include <cstdio>
 
 using namespace detbox;
 
@@ -252,30 +250,61 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_segments_generic_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // Fast path: unsorted segments of at most 256*JPT boxes, threshold >= 0.
+//
 // Every thread keeps its JPT boxes (sorted positions tid, tid+256, ...) in registers for the whole
-// sweep; the boxes a chunk keeps are compacted into a small LDS array and broadcast, so one LDS read
-// serves JPT pair tests.  The pair test avoids the fp32 division: with u = (area_i + area_j) - inter
-// (the reference's own operations) and p = fl(thr * u),
-//     inter > p * (1 + 2^-21)  =>  fl(inter / u) > thr,     inter < p * (1 - 2^-21)  =>  fl(inter / u) <= thr
-// (the margins dominate the roundings of p and of the products), and only the sliver in between
-// -- or a tiny/non-positive p -- falls back to the reference's division.  Results are bit-identical.
+// sweep.  Per 64-box chunk (in sorted order): the mutual suppression words of the chunk, a wave-serial
+// resolve over the rows that suppress anything, then the boxes the chunk keeps are broadcast with
+// readlane against every later box still alive (wave-uniform 64-bit alive masks per register slot).
+//
+// The pair test is two-staged.  Stage 1 is a conservative integer reject on boxes quantised to 16 bits
+// over the segment's extent (outer boxes: low edges rounded down, high edges up), two coordinates per
+// packed instruction:  inter_up = w_q * h_q  is an upper bound of the intersection in grid units, and
+//     iou > thr  =>  inter * (1 + thr) > thr * (area_i + area_j)  =>  inter_up > T_i + T_j,
+// T = floor(thr' / (1 + thr') * area * (1 - eps)) per box with thr' a hair below thr; so
+// inter_up <= T_i + T_j proves "not suppressed".  Stage 2 runs only while some lane is undecided and is
+// the reference's own fp32 arithmetic (division-free where the margins decide, the division itself in
+// the sliver that is left).  The results are the reference's, bit for bit.
 // ---------------------------------------------------------------------------------------------
 
-__device__ inline bool suppresses(const float4 bi, const float ai, const float4 bj, const float aj, const float thr) {
-    const float w = fminf(bi.z, bj.z) - fmaxf(bi.x, bj.x);
-    const float h = fminf(bi.w, bj.w) - fmaxf(bi.y, bj.y);
-    if (!(w > 0.0f && h > 0.0f)) return false;          // inter == 0 (or NaN): iou is 0 or NaN, never > thr >= 0
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ inline u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+
+// `i` is the kept (earlier) box.  k_hi / k_lo: thr widened by 2^-20 either way; u_min guards tiny unions.
+__device__ inline bool suppresses_nodiv(const float4 bi, const float ai, const float4 bj, const float thr,
+                                        const float k_hi, const float k_lo, const float u_min) {
+    const float w = fmaxf(fminf(bi.z, bj.z) - fmaxf(bi.x, bj.x), 0.0f);
+    const float h = fminf(bi.w, bj.w) - fmaxf(bi.y, bj.y);     // unclamped: h < 0 gives inter <= 0, a "no"
+    const float aj = (bj.z - bj.x) * (bj.w - bj.y);
     const float inter = w * h;
     const float u = (ai + aj) - inter;
-    const float p = thr * u;
-    if (p > 1e-30f) {
-        if (inter > p * 1.0000005f) return true;
-        if (inter < p * 0.9999995f) return false;
+    if (u > u_min) {
+        if (inter > u * k_hi) return true;
+        if (inter < u * k_lo) return false;
     }
-    return inter / u > thr;
+    const float it = w * fmaxf(h, 0.0f);
+    return it / ((ai + aj) - it) > thr;
 }
 
-struct NmsFastLds { size_t keys, box, area, kbox, karea, removed, maskq, misc, wprefix, total; };
+// Quantisation of one box: outer box on a 16-bit grid and its threshold share T.
+struct QBox { uint32_t lo, hi, T; };
+
+__device__ inline QBox quantise_box(const float4 bx, const float area, const float x0, const float y0, const float scale,
+                                    const float t_scale, const bool ok) {
+    QBox q;
+    if (!ok) { q.lo = 0u; q.hi = 0xffffffffu; q.T = 0u; return q; }        // never rejects anything
+    const float fx1 = floorf((bx.x - x0) * scale - 0.0625f), fy1 = floorf((bx.y - y0) * scale - 0.0625f);
+    const float fx2 = ceilf((bx.z - x0) * scale + 0.0625f), fy2 = ceilf((bx.w - y0) * scale + 0.0625f);
+    const uint32_t x1 = (uint32_t)fminf(fmaxf(fx1, 0.0f), 65535.0f), y1 = (uint32_t)fminf(fmaxf(fy1, 0.0f), 65535.0f);
+    const uint32_t x2 = (uint32_t)fminf(fmaxf(fx2, 0.0f), 65535.0f), y2 = (uint32_t)fminf(fmaxf(fy2, 0.0f), 65535.0f);
+    q.lo = (y1 << 16) | x1;
+    q.hi = (y2 << 16) | x2;
+    const float t = area * t_scale;                                         // NaN or <= 0 -> 0
+    q.T = t > 0.0f ? (uint32_t)fminf(t, 2147483648.0f) : 0u;
+    return q;
+}
+
+struct NmsFastLds { size_t keys, box, kbox, removed, mask, misc, wprefix, total; };
 
 __host__ __device__ inline NmsFastLds nms_fast_lds(int max_seg, int n2) {
     const size_t words_cap = (size_t)((max_seg + 63) >> 6);
@@ -283,12 +312,10 @@ __host__ __device__ inline NmsFastLds nms_fast_lds(int max_seg, int n2) {
     size_t off = 0;
     l.keys = off;    off += (size_t)n2 * 8;
     l.box = off;     off += (size_t)max_seg * 16;
-    l.area = off;    off += (((size_t)max_seg * 4 + 15) & ~(size_t)15);
     l.kbox = off;    off += 64 * 16;
-    l.karea = off;   off += 64 * 4;
     l.removed = off; off += ((words_cap * 8 + 15) & ~(size_t)15);
-    l.maskq = off;   off += 256 * 8;
-    l.misc = off;    off += 16;                                       // keep word, kept count
+    l.mask = off;    off += 64 * 8;
+    l.misc = off;    off += 96;                                       // keep word; 4 x 4 floats of the extent reduction
     l.wprefix = off; off += ((words_cap * 4 + 15) & ~(size_t)15);
     l.total = off;
     return l;
@@ -313,18 +340,23 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_segments_fast_kernel(
     char *lds_base = reinterpret_cast<char *>(s_dyn);
     unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(lds_base + ld.keys);
     float4 *s_box = reinterpret_cast<float4 *>(lds_base + ld.box);
-    float *s_area = reinterpret_cast<float *>(lds_base + ld.area);
     float4 *s_kbox = reinterpret_cast<float4 *>(lds_base + ld.kbox);
-    float *s_karea = reinterpret_cast<float *>(lds_base + ld.karea);
     unsigned long long *s_removed = reinterpret_cast<unsigned long long *>(lds_base + ld.removed);
-    unsigned long long *s_maskq = reinterpret_cast<unsigned long long *>(lds_base + ld.maskq);
+    unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(lds_base + ld.mask);
     unsigned long long *s_keepw = reinterpret_cast<unsigned long long *>(lds_base + ld.misc);
+    float *s_red = reinterpret_cast<float *>(lds_base + ld.misc + 16);
     uint32_t *s_wprefix = reinterpret_cast<uint32_t *>(lds_base + ld.wprefix);
 
     const size_t row0 = (size_t)b * np.stride + seg0;
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
     const int words = (n + 63) >> 6;
     const float thr = np.thr;
+    // Division-free decision: with u = (area_i + area_j) - inter > u_min,
+    //   inter > u * k_hi  =>  fl(inter / u) > thr      and      inter < u * k_lo  =>  fl(inter / u) <= thr,
+    // k_hi / k_lo being thr widened by 2^-20 either way (the roundings of the products stay below 2^-22).
+    const float k_hi = thr * 1.000001f, k_lo = thr * 0.999999f;
+    const float u_min = thr > 0.0f ? 1e-30f / thr : __builtin_inff();
 
     int n2 = 2;
     while (n2 < n) n2 <<= 1;
@@ -340,6 +372,7 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_segments_fast_kernel(
     // boxes in sorted order: LDS copy for the chunk phases, register copy of the thread's own boxes
     float4 bj[JPT];
     float aj[JPT];
+    float lx = __builtin_inff(), ly = __builtin_inff(), hx = -__builtin_inff(), hy = -__builtin_inff();
 #pragma unroll
     for (int m = 0; m < JPT; ++m) {
         const int j = tid + m * NMS_BLOCK;
@@ -350,281 +383,11 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_segments_fast_kernel(
             bj[m] = boxes[row0 + o];
             aj[m] = (bj[m].z - bj[m].x) * (bj[m].w - bj[m].y);
             s_box[j] = bj[m];
-            s_area[j] = aj[m];
+            lx = fminf(lx, bj[m].x); ly = fminf(ly, bj[m].y); hx = fmaxf(hx, bj[m].z); hy = fmaxf(hy, bj[m].w);
         }
     }
-    for (int i = tid; i < words; i += NMS_BLOCK) s_removed[i] = 0ull;
-    __syncthreads();
-
-    unsigned rem_mask = 0u;                               // bit m: own box m is suppressed
-    const int lane = tid & 63, q = tid >> 6;
-    // Division-free decision: with u = (area_i + area_j) - inter > u_min,
-    //   inter > u * k_hi  =>  fl(inter / u) > thr      and      inter < u * k_lo  =>  fl(inter / u) <= thr,
-    // k_hi / k_lo being thr widened by 2^-20 either way (the roundings of the products stay below 2^-22).
-    const float k_hi = thr * 1.000001f, k_lo = thr * 0.999999f;
-    const float u_min = thr > 0.0f ? 1e-30f / thr : __builtin_inff();
-    for (int ch = 0; ch < words; ++ch) {
-        const int c0 = ch << 6;
-        const int cn = min(64, n - c0);
-        const unsigned long long valid = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
-        const unsigned long long alive0 = ~s_removed[ch] & valid;
-        {   // 64x64 suppression words of this chunk: thread (lane, q) covers columns q*16..q*16+15
-            unsigned long long part = 0ull;
-            if (lane < cn && ((alive0 >> lane) & 1ull)) {
-                const float4 bi = s_box[c0 + lane];
-                const float ai = s_area[c0 + lane];
-                const int j0 = max(q * 16, lane + 1), j1 = min(q * 16 + 16, cn);
-                for (int j = j0; j < j1; ++j)
-                    if (suppresses(bi, ai, s_box[c0 + j], s_area[c0 + j], thr)) part |= 1ull << j;
-            }
-            s_maskq[q * 64 + lane] = part;
-        }
-        __syncthreads();
-        if (q == 0) {
-            const unsigned long long m = s_maskq[lane] | s_maskq[64 + lane] | s_maskq[128 + lane] | s_maskq[192 + lane];
-            unsigned long long alive = uniform64(alive0);
-            unsigned long long keep = 0ull;
-            while (alive) {
-                const int i = __ffsll((long long)alive) - 1;
-                keep |= 1ull << i;
-                alive &= ~readlane64(m, i);
-                alive &= ~(1ull << i);
-            }
-            if ((keep >> lane) & 1ull) {                  // compact the kept boxes of the chunk
-                const int r = __popcll(keep & ((1ull << lane) - 1ull));
-                s_kbox[r] = s_box[c0 + lane];
-                s_karea[r] = s_area[c0 + lane];
-            }
-            if (lane == 0) { s_keepw[0] = keep; s_removed[ch] = valid & ~keep; }
-        }
-        __syncthreads();
-        const int nk = __popcll(s_keepw[0]);
-        // The kept boxes of this chunk against every later box still alive.  The later boxes are the
-        // lanes' own register boxes; kept box t is broadcast with readlane from a register image of the
-        // kept list; which lanes are still alive is a wave-uniform 64-bit mask per register slot, so
-        // all bookkeeping is scalar and a slot whose lanes are all settled is skipped.
-        if (nk > 0) {
-            const float4 kb = lane < nk ? s_kbox[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float ka = lane < nk ? s_karea[lane] : 0.f;
-            unsigned long long act[JPT];
-            bool any_act = false;
-#pragma unroll
-            for (int m = 0; m < JPT; ++m) {
-                const int j = tid + m * NMS_BLOCK;
-                act[m] = __ballot(j >= c0 + 64 && j < n && !((rem_mask >> m) & 1u));
-                any_act |= act[m] != 0ull;
-            }
-            if (any_act) {
-                unsigned long long hit[JPT];
-#pragma unroll
-                for (int m = 0; m < JPT; ++m) hit[m] = 0ull;
-                for (int t = 0; t < nk; ++t) {
-                    const float ix1 = readlane_f(kb.x, t), iy1 = readlane_f(kb.y, t);
-                    const float ix2 = readlane_f(kb.z, t), iy2 = readlane_f(kb.w, t);
-                    const float ai = readlane_f(ka, t);
-#pragma unroll
-                    for (int m = 0; m < JPT; ++m) {
-                        if (act[m]) {                                   // wave-uniform
-                            // One clamp is enough: with w >= 0, a negative h makes inter <= 0, which is a "no".
-                            const float w = vmax_raw(vmin_raw(ix2, bj[m].z) - vmax_raw(ix1, bj[m].x), 0.0f);
-                            const float h = vmin_raw(iy2, bj[m].w) - vmax_raw(iy1, bj[m].y);
-                            const float inter = w * h;
-                            const float u = (ai + aj[m]) - inter;
-                            const unsigned long long sane = __ballot(u > u_min);
-                            unsigned long long yes = __ballot(inter > u * k_hi) & sane;
-                            const unsigned long long no = __ballot(inter < u * k_lo) & sane;
-                            const unsigned long long amb = act[m] & ~(yes | no);
-                            if (amb) {                                   // the sliver the margins leave: the reference's own test
-                                const float wc = fmaxf(w, 0.0f), hc = fmaxf(h, 0.0f);
-                                const float it = wc * hc;
-                                yes |= __ballot(it / ((ai + aj[m]) - it) > thr) & amb;
-                            }
-                            yes &= act[m];
-                            act[m] &= ~yes;
-                            hit[m] |= yes;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < JPT; ++m) {
-                    if ((hit[m] >> lane) & 1ull) {
-                        const int j = tid + m * NMS_BLOCK;
-                        rem_mask |= 1u << m;
-                        atomicOr(&s_removed[j >> 6], 1ull << (j & 63));
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    // kept = not removed; compact in sorted order
-    if (q == 0) {
-        uint32_t running = 0;
-        for (int base = 0; base < words; base += 64) {
-            const int w = base + lane;
-            uint32_t pc = 0;
-            if (w < words) {
-                const int cn = min(64, n - (w << 6));
-                const unsigned long long valid = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
-                pc = (uint32_t)__popcll(~s_removed[w] & valid);
-            }
-            uint32_t inc = pc;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t up = __shfl_up(inc, o);
-                if (lane >= o) inc += up;
-            }
-            if (w < words) s_wprefix[w] = running + inc - pc;
-            running += __shfl(inc, 63);
-        }
-        if (lane == 0) kcount[(size_t)b * np.S + s] = (int32_t)running;
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += NMS_BLOCK) {
-        const unsigned long long rem = s_removed[i >> 6];
-        if ((rem >> (i & 63)) & 1ull) continue;
-        const uint32_t rank = s_wprefix[i >> 6] + (uint32_t)__popcll(~rem & ((1ull << (i & 63)) - 1ull));
-        const int pos = seg0 + (int)(0xffffffffu - (uint32_t)(s_keys[i] & 0xffffffffull));
-        kept[row0 + rank] = make_float2(scores[(size_t)b * np.stride + pos], __int_as_float(pos));
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Grid path: unsorted segments of at most DETBOX_NMS_MAX_SORT boxes, threshold >= 0.
-//
-// Greedy NMS only ever needs a kept box tested against the later boxes it can overlap.  All boxes of
-// the segment are binned once into a small pyramid of uniform grids (level L has 2^L x 2^L cells over
-// the segment's extent; a box goes to the deepest level whose cell is at least as large as its longer
-// side, into the cell of its centre; per level the cells are laid out row-major in one CSR array).  A
-// box of level L that overlaps a kept box k has its centre within half a level-L cell of k, so k only
-// visits the few cells of every level around itself -- and skips whole levels whose boxes are too
-// small or too large to reach the IoU threshold against k's area.  The sweep keeps the chunk structure
-// of the sequential algorithm: 64 boxes at a time in sorted order, their mutual 64x64 suppression
-// words first, then the boxes the chunk keeps knock out later boxes through the grid.
-// The decisions are the reference's, bit for bit: the grid only removes pairs that cannot overlap.
-// ---------------------------------------------------------------------------------------------
-
-static __device__ long long g_nms_dbg[16];
-#define DBG_T(k) if (dbg_on) { const long long now_ = clock64(); g_nms_dbg[k] += now_ - t_last; t_last = now_; }
-constexpr int GRID_LEVELS = 6;
-constexpr int GRID_CELLS = 1365;          // (4^6 - 1) / 3
-constexpr int GRID_CELLS_PAD = 1368;
-
-struct NmsGridLds { size_t cell, mask, removed, wprefix, misc, kbox, aux_total, box, cpos, orig, total; };
-
-__host__ __device__ inline NmsGridLds nms_grid_lds(int max_seg, int n2) {
-    const size_t words_cap = (size_t)((max_seg + 63) >> 6);
-    NmsGridLds l;
-    size_t off = 0;                        // region A: the sort keys first, these afterwards
-    l.cell = off;    off += (size_t)GRID_CELLS_PAD * 4;
-    l.mask = off;    off += 64 * 8;
-    l.removed = off; off += ((words_cap * 8 + 15) & ~(size_t)15);
-    l.wprefix = off; off += ((words_cap * 4 + 15) & ~(size_t)15);
-    l.misc = off;    off += 256;
-    l.kbox = off;    off += 64 * 16;
-    l.aux_total = off;
-    size_t a = (size_t)n2 * 8;
-    if (a < l.aux_total) a = l.aux_total;
-    off = (a + 15) & ~(size_t)15;
-    l.box = off;     off += (size_t)max_seg * 16;
-    l.cpos = off;    off += (((size_t)max_seg * 2 + 15) & ~(size_t)15);
-    l.orig = off;    off += (((size_t)max_seg * 2 + 15) & ~(size_t)15);
-    l.total = off;
-    return l;
-}
-
-// The reference's test `inter / ((ai + aj) - inter) > thr` without the division wherever the margins
-// k_hi / k_lo (thr widened by 2^-20 either way) already decide it; `i` is the kept (earlier) box.
-__device__ inline bool suppresses_nodiv(const float4 bi, const float ai, const float4 bj, const float thr,
-                                        const float k_hi, const float k_lo, const float u_min) {
-    const float w = fmaxf(fminf(bi.z, bj.z) - fmaxf(bi.x, bj.x), 0.0f);
-    const float h = fminf(bi.w, bj.w) - fmaxf(bi.y, bj.y);     // unclamped: h < 0 gives inter <= 0, a "no"
-    const float aj = (bj.z - bj.x) * (bj.w - bj.y);
-    const float inter = w * h;
-    const float u = (ai + aj) - inter;
-    if (u > u_min) {
-        if (inter > u * k_hi) return true;
-        if (inter < u * k_lo) return false;
-    }
-    const float it = w * fmaxf(h, 0.0f);
-    return it / ((ai + aj) - it) > thr;
-}
-
-__device__ inline int grid_cell(float v, float origin, float inv, int cells) {
-    const int i = (int)((v - origin) * inv);                    // monotone in v; NaN -> 0
-    return min(max(i, 0), cells - 1);
-}
-
-template <int JPT>
-__global__ __launch_bounds__(NMS_BLOCK) void nms_segments_cull_kernel(
-    const float4 *__restrict__ boxes, const float *__restrict__ scores, const int32_t *__restrict__ seg_off,
-    NmsParams np, float2 *__restrict__ kept, int32_t *__restrict__ kcount, int32_t *__restrict__ err) {
-    extern __shared__ unsigned long long s_dyn[];
-    const int s = blockIdx.x, b = blockIdx.y;
-    const int32_t *so = seg_off + (size_t)b * (np.S + 1);
-    const int seg0 = so[s];
-    const int n = so[s + 1] - seg0;
-    if (threadIdx.x == 0) kcount[(size_t)b * np.S + s] = 0;
-    if (n <= 0) return;
-    if (n > np.max_seg) {
-        if (threadIdx.x == 0) err[b] = 1;
-        return;
-    }
-    const NmsGridLds ld = nms_grid_lds(np.max_seg, np.n2);
-    char *lds_base = reinterpret_cast<char *>(s_dyn);
-    unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(lds_base);
-    uint32_t *s_cell = reinterpret_cast<uint32_t *>(lds_base + ld.cell);
-    unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(lds_base + ld.mask);
-    unsigned long long *s_removed = reinterpret_cast<unsigned long long *>(lds_base + ld.removed);
-    uint32_t *s_wprefix = reinterpret_cast<uint32_t *>(lds_base + ld.wprefix);
-    unsigned long long *s_keepw = reinterpret_cast<unsigned long long *>(lds_base + ld.misc);         // 8 B
-    uint16_t *s_kpos = reinterpret_cast<uint16_t *>(lds_base + ld.misc + 16);                          // 128 B
-    float *s_red = reinterpret_cast<float *>(lds_base + ld.misc + 144);                                // 4 x 4 floats
-    uint32_t *s_amin = reinterpret_cast<uint32_t *>(lds_base + ld.misc + 208);                         // 6 words
-    uint32_t *s_wsum = reinterpret_cast<uint32_t *>(lds_base + ld.misc + 240);                         // 4 words
-    float4 *s_kbox = reinterpret_cast<float4 *>(lds_base + ld.kbox);
-    float4 *s_box = reinterpret_cast<float4 *>(lds_base + ld.box);
-    uint16_t *s_cpos = reinterpret_cast<uint16_t *>(lds_base + ld.cpos);
-    uint16_t *s_orig = reinterpret_cast<uint16_t *>(lds_base + ld.orig);
-
-    const size_t row0 = (size_t)b * np.stride + seg0;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
-    const int words = (n + 63) >> 6;
-    const float thr = np.thr;
-    const float k_hi = thr * 1.000001f, k_lo = thr * 0.999999f;
-    const float u_min = thr > 0.0f ? 1e-30f / thr : __builtin_inff();
-
-    const bool dbg_on = tid == 0 && s == 3 && b == 1;
-    long long t_last = clock64();
-    int n2 = 2;
-    while (n2 < n) n2 <<= 1;
-    for (int i = tid; i < n2; i += NMS_BLOCK) {
-        unsigned long long k = 0ull;
-        if (i < n)   // every real key is above the zero padding: its low word is 0xffffffff - i > 0
-            k = ((unsigned long long)okey_from_bits(__float_as_uint(scores[row0 + i])) << 32) |
-                (unsigned long long)(0xffffffffu - (uint32_t)i);
-        s_keys[i] = k;
-    }
-    __syncthreads();
-    bitonic_desc_u64(s_keys, n2);
-    DBG_T(0)
-    // boxes in sorted order; the original position of every sorted slot
-    float lx = __builtin_inff(), ly = __builtin_inff(), hx = -__builtin_inff(), hy = -__builtin_inff();
-    for (int j = tid; j < n; j += NMS_BLOCK) {
-        const uint32_t o = 0xffffffffu - (uint32_t)(s_keys[j] & 0xffffffffull);
-        const float4 bx = boxes[row0 + o];
-        s_orig[j] = (uint16_t)o;
-        s_box[j] = bx;
-        lx = fminf(lx, bx.x); ly = fminf(ly, bx.y); hx = fmaxf(hx, bx.z); hy = fmaxf(hy, bx.w);
-    }
-    __syncthreads();                                                        // the keys are dead from here on
-    DBG_T(1)
-    const bool use_grid = words > 1;
-    for (int i = tid; i < GRID_CELLS_PAD; i += NMS_BLOCK) s_cell[i] = 0u;
     for (int i = tid; i < words; i += NMS_BLOCK) s_removed[i] = 0ull;
     if (tid < 64) s_mask[tid] = 0ull;
-    if (tid < GRID_LEVELS) s_amin[tid] = 0x7f800000u;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         lx = fminf(lx, __shfl_xor(lx, o)); ly = fminf(ly, __shfl_xor(ly, o));
@@ -636,110 +399,21 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_segments_cull_kernel(
     ly = fminf(fminf(s_red[1], s_red[5]), fminf(s_red[9], s_red[13]));
     hx = fmaxf(fmaxf(s_red[2], s_red[6]), fmaxf(s_red[10], s_red[14]));
     hy = fmaxf(fmaxf(s_red[3], s_red[7]), fmaxf(s_red[11], s_red[15]));
-    // Extent E of the segment; the grid is switched off (every box in cell 0 of level 0: plain all-pairs)
-    // when E is not a sane positive number or so small against the coordinates that the half-cell
-    // margins would drown in rounding.
+    // 16-bit grid over the extent of the segment; switched off (nothing is ever rejected early) when the
+    // extent is not a sane positive number
     const float E = fmaxf(hx - lx, hy - ly);
-    const float maxabs = fmaxf(fmaxf(fabsf(lx), fabsf(hx)), fmaxf(fabsf(ly), fabsf(hy)));
-    const bool grid_ok = use_grid && E > 1e-30f && E < 1e30f && E >= maxabs * (1.0f / 256.0f);
-    const float inv0 = grid_ok ? 1.0f / E : 0.0f;
-
-    if (use_grid) {
-        // level and cell of a box: the deepest level whose cell side covers 1.01 x the longer box side
-        auto cell_of = [&](const float4 bx, int &level) -> int {
-            const float m = fmaxf(bx.z - bx.x, bx.w - bx.y) * 1.01f;
-            int L = 0;
-            float c = E;
-            if (grid_ok)
-                while (L < GRID_LEVELS - 1 && c * 0.5f >= m) { c *= 0.5f; ++L; }
-            level = L;
-            const float inv = inv0 * (float)(1 << L);
-            const int ix = grid_cell(0.5f * (bx.x + bx.z), lx, inv, 1 << L);
-            const int iy = grid_cell(0.5f * (bx.y + bx.w), ly, inv, 1 << L);
-            return ((1 << (2 * L)) - 1) / 3 + (iy << L) + ix;
-        };
-        for (int j = tid; j < n; j += NMS_BLOCK) {
-            const float4 bx = s_box[j];
-            int L;
-            const int id = cell_of(bx, L);
-            atomicAdd(&s_cell[id], 1u);
-            const float a = (bx.z - bx.x) * (bx.w - bx.y);
-            atomicMin(&s_amin[L], a > 0.0f ? __float_as_uint(a) : 0u);       // positive floats order like their bits
-        }
-        __syncthreads();
-        {   // exclusive scan of the cell counts (6 cells per thread)
-            uint32_t loc[6], sum = 0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int idx = tid * 6 + k;
-                loc[k] = idx < GRID_CELLS_PAD ? s_cell[idx] : 0u;
-                sum += loc[k];
-            }
-            uint32_t inc = sum;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t up = __shfl_up(inc, o);
-                if (lane >= o) inc += up;
-            }
-            if (lane == 63) s_wsum[wv] = inc;
-            __syncthreads();
-            uint32_t base = 0;
-            for (int w = 0; w < wv; ++w) base += s_wsum[w];
-            uint32_t ex = base + inc - sum;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int idx = tid * 6 + k;
-                if (idx < GRID_CELLS_PAD) s_cell[idx] = ex;
-                ex += loc[k];
-            }
-        }
-        __syncthreads();
-        for (int j = tid; j < n; j += NMS_BLOCK) {
-            int L;
-            const int id = cell_of(s_box[j], L);
-            s_cpos[atomicAdd(&s_cell[id], 1u)] = (uint16_t)j;               // afterwards s_cell[id] = END of cell id
-        }
-    }
-    __syncthreads();
-    DBG_T(2)
-    // Every thread owns JPT boxes for the whole sweep, in registers.  Ownership follows the grid order, so
-    // the 64 boxes of one register slot of one wave are neighbours in space: each slot has a tight
-    // bounding box and area range, and a kept box is only tested against the slots (and waves) it can
-    // reach.  Lane m of sb_* holds the bounds of this wave's slot m; rg_* are the bounds of the wave.
-    float4 bj[JPT];
-    float aj[JPT];
-    int pos[JPT];
-    float sb_x1 = 0.f, sb_y1 = 0.f, sb_x2 = 0.f, sb_y2 = 0.f, sb_amin = 0.f, sb_amax = 0.f;
-    float rg_x1 = __builtin_inff(), rg_y1 = __builtin_inff(), rg_x2 = -__builtin_inff(), rg_y2 = -__builtin_inff();
-    float rg_amin = __builtin_inff(), rg_amax = -__builtin_inff();
+    const bool q_ok = E > 1e-30f && E < 1e30f;
+    const float scale = q_ok ? 65535.0f / E : 0.0f;
+    const float thr_q = fminf(thr * 0.9999f, 1.0f);
+    const float t_scale = (thr_q / (1.0f + thr_q)) * scale * scale * 0.9999f;
+    uint32_t qlo[JPT], qhi[JPT], qT[JPT];
 #pragma unroll
     for (int m = 0; m < JPT; ++m) {
-        const int q = (wv * JPT + m) * 64 + lane;
-        bj[m] = make_float4(0.f, 0.f, 0.f, 0.f);
-        aj[m] = 0.f;
-        pos[m] = -1;
-        float x1 = __builtin_inff(), y1 = __builtin_inff(), x2 = -__builtin_inff(), y2 = -__builtin_inff();
-        float amn = __builtin_inff(), amx = -__builtin_inff();
-        if (use_grid && q < n) {
-            const int j = s_cpos[q];
-            pos[m] = j;
-            bj[m] = s_box[j];
-            aj[m] = (bj[m].z - bj[m].x) * (bj[m].w - bj[m].y);
-            x1 = bj[m].x; y1 = bj[m].y; x2 = bj[m].z; y2 = bj[m].w; amn = aj[m]; amx = aj[m];
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            x1 = fminf(x1, __shfl_xor(x1, o)); y1 = fminf(y1, __shfl_xor(y1, o));
-            x2 = fmaxf(x2, __shfl_xor(x2, o)); y2 = fmaxf(y2, __shfl_xor(y2, o));
-            amn = fminf(amn, __shfl_xor(amn, o)); amx = fmaxf(amx, __shfl_xor(amx, o));
-        }
-        if (lane == m) { sb_x1 = x1; sb_y1 = y1; sb_x2 = x2; sb_y2 = y2; sb_amin = amn; sb_amax = amx; }
-        rg_x1 = fminf(rg_x1, x1); rg_y1 = fminf(rg_y1, y1); rg_x2 = fmaxf(rg_x2, x2); rg_y2 = fmaxf(rg_y2, y2);
-        rg_amin = fminf(rg_amin, amn); rg_amax = fmaxf(rg_amax, amx);
+        const QBox q = quantise_box(bj[m], aj[m], lx, ly, scale, t_scale, q_ok);
+        qlo[m] = q.lo; qhi[m] = q.hi; qT[m] = q.T;
     }
-    unsigned rem_mask = 0u;                               // bit m: own box m is suppressed
-    const float thr99 = thr * 0.99f;
 
+    unsigned rem_mask = 0u;                               // bit m: own box m is suppressed
     for (int ch = 0; ch < words; ++ch) {
         const int c0 = ch << 6;
         const int cn = min(64, n - c0);
@@ -759,7 +433,6 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_segments_cull_kernel(
             }
         }
         __syncthreads();
-        DBG_T(3)
         if (wv == 0) {
             const unsigned long long m = s_mask[lane];
             s_mask[lane] = 0ull;
@@ -774,69 +447,74 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_segments_cull_kernel(
             if (lane == 0) { s_keepw[0] = keep; s_removed[ch] = valid & ~keep; }
         }
         __syncthreads();
-        DBG_T(4)
         const int nk = __popcll(s_keepw[0]);
-        if (use_grid && nk > 0 && ch + 1 < words) {
+        // The kept boxes of this chunk against every later box still alive.  The later boxes are the
+        // lanes' own register boxes; kept box t is broadcast with readlane from a register image of the
+        // kept list; which lanes are still alive is a wave-uniform 64-bit mask per register slot, so
+        // all bookkeeping is scalar and a slot whose lanes are all settled is skipped.
+        if (nk > 0 && ch + 1 < words) {
             unsigned long long act[JPT];
             bool any_act = false;
 #pragma unroll
             for (int m = 0; m < JPT; ++m) {
-                act[m] = __ballot(pos[m] >= c0 + 64 && !((rem_mask >> m) & 1u));
+                const int j = tid + m * NMS_BLOCK;
+                act[m] = __ballot(j >= c0 + 64 && j < n && !((rem_mask >> m) & 1u));
                 any_act |= act[m] != 0ull;
             }
             if (any_act) {
                 const float4 kb = lane < nk ? s_kbox[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float ka = (kb.z - kb.x) * (kb.w - kb.y);
-                // kept boxes that can reach this wave's boxes at all: overlap of the bounds, compatible areas
-                unsigned long long rel = __ballot(lane < nk && fminf(kb.z, rg_x2) - fmaxf(kb.x, rg_x1) > 0.0f &&
-                                                  fminf(kb.w, rg_y2) - fmaxf(kb.y, rg_y1) > 0.0f &&
-                                                  rg_amax > thr99 * ka && ka > thr99 * rg_amin);
+                const QBox kq = quantise_box(kb, ka, lx, ly, scale, t_scale, q_ok);
                 unsigned long long hit[JPT];
 #pragma unroll
                 for (int m = 0; m < JPT; ++m) hit[m] = 0ull;
-                while (rel) {
-                    const int t = __ffsll((long long)rel) - 1;
-                    rel &= rel - 1ull;
-                    const float ix1 = readlane_f(kb.x, t), iy1 = readlane_f(kb.y, t);
-                    const float ix2 = readlane_f(kb.z, t), iy2 = readlane_f(kb.w, t);
-                    const float ai = readlane_f(ka, t);
-                    const unsigned slots = (unsigned)__ballot(lane < JPT && fminf(ix2, sb_x2) - fmaxf(ix1, sb_x1) > 0.0f &&
-                                                              fminf(iy2, sb_y2) - fmaxf(iy1, sb_y1) > 0.0f &&
-                                                              sb_amax > thr99 * ai && ai > thr99 * sb_amin);
+                for (int t = 0; t < nk; ++t) {
+                    const uint32_t klo = __builtin_amdgcn_readlane(kq.lo, t), khi = __builtin_amdgcn_readlane(kq.hi, t);
+                    const uint32_t kT = __builtin_amdgcn_readlane(kq.T, t);
 #pragma unroll
                     for (int m = 0; m < JPT; ++m) {
-                        if (((slots >> m) & 1u) && act[m]) {                 // wave-uniform
-                            // One clamp is enough: with w >= 0, a negative h makes inter <= 0, which is a "no".
-                            const float w = vmax_raw(vmin_raw(ix2, bj[m].z) - vmax_raw(ix1, bj[m].x), 0.0f);
-                            const float h = vmin_raw(iy2, bj[m].w) - vmax_raw(iy1, bj[m].y);
-                            const float inter = w * h;
-                            const float u = (ai + aj[m]) - inter;
-                            const unsigned long long sane = __ballot(u > u_min);
-                            unsigned long long yes = __ballot(inter > u * k_hi) & sane;
-                            const unsigned long long no = __ballot(inter < u * k_lo) & sane;
-                            const unsigned long long amb = act[m] & ~(yes | no);
-                            if (amb) {                                   // the sliver the margins leave: the reference's own test
-                                const float it = w * fmaxf(h, 0.0f);
-                                yes |= __ballot(it / ((ai + aj[m]) - it) > thr) & amb;
+                        if (act[m]) {                                   // wave-uniform
+                            // stage 1: integer upper bound of the intersection against the threshold shares
+                            const u16x2 lo = __builtin_elementwise_max(as_u16x2(klo), as_u16x2(qlo[m]));
+                            const u16x2 hi = __builtin_elementwise_min(as_u16x2(khi), as_u16x2(qhi[m]));
+                            const u16x2 d = __builtin_elementwise_sub_sat(hi, lo);
+                            const uint32_t inter_up = (uint32_t)d.x * (uint32_t)d.y;
+                            const unsigned long long open = act[m] & ~__ballot(inter_up <= kT + qT[m]);
+                            if (open) {                                  // stage 2: the reference's arithmetic
+                                const float ix1 = readlane_f(kb.x, t), iy1 = readlane_f(kb.y, t);
+                                const float ix2 = readlane_f(kb.z, t), iy2 = readlane_f(kb.w, t);
+                                const float ai = readlane_f(ka, t);
+                                // One clamp is enough: with w >= 0, a negative h makes inter <= 0, which is a "no".
+                                const float w = fmaxf(fminf(ix2, bj[m].z) - fmaxf(ix1, bj[m].x), 0.0f);
+                                const float h = fminf(iy2, bj[m].w) - fmaxf(iy1, bj[m].y);
+                                const float inter = w * h;
+                                const float u = (ai + aj[m]) - inter;
+                                const unsigned long long sane = __ballot(u > u_min);
+                                unsigned long long yes = __ballot(inter > u * k_hi) & sane;
+                                const unsigned long long no = __ballot(inter < u * k_lo) & sane;
+                                const unsigned long long amb = open & ~(yes | no);
+                                if (amb) {                               // the sliver the margins leave: the reference's own test
+                                    const float it = w * fmaxf(h, 0.0f);
+                                    yes |= __ballot(it / ((ai + aj[m]) - it) > thr) & amb;
+                                }
+                                yes &= open;
+                                act[m] &= ~yes;
+                                hit[m] |= yes;
                             }
-                            yes &= act[m];
-                            act[m] &= ~yes;
-                            hit[m] |= yes;
                         }
                     }
                 }
 #pragma unroll
                 for (int m = 0; m < JPT; ++m) {
                     if ((hit[m] >> lane) & 1ull) {
+                        const int j = tid + m * NMS_BLOCK;
                         rem_mask |= 1u << m;
-                        atomicOr(&s_removed[pos[m] >> 6], 1ull << (pos[m] & 63));
+                        atomicOr(&s_removed[j >> 6], 1ull << (j & 63));
                     }
                 }
             }
         }
-        DBG_T(5)
         __syncthreads();
-        DBG_T(6)
     }
     // kept = not removed; compact in sorted order
     if (wv == 0) {
@@ -865,10 +543,9 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_segments_cull_kernel(
         const unsigned long long rem = s_removed[i >> 6];
         if ((rem >> (i & 63)) & 1ull) continue;
         const uint32_t rank = s_wprefix[i >> 6] + (uint32_t)__popcll(~rem & ((1ull << (i & 63)) - 1ull));
-        const int pos = seg0 + (int)s_orig[i];
+        const int pos = seg0 + (int)(0xffffffffu - (uint32_t)(s_keys[i] & 0xffffffffull));
         kept[row0 + rank] = make_float2(scores[(size_t)b * np.stride + pos], __int_as_float(pos));
     }
-    DBG_T(7)
 }
 
 __global__ __launch_bounds__(256) void nms_scan_kernel(const int32_t *__restrict__ kcount, int S,
@@ -1035,31 +712,7 @@ extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scor
         ProfScope ps("nms_segments", st);
         dim3 grid((unsigned)S, (unsigned)B);
         const float4 *b4 = reinterpret_cast<const float4 *>(boxes);
-        if (fast && !getenv("DETBOX_NMS_OLD")) {
-            const size_t lds = nms_grid_lds(np.max_seg, np.n2).total;
-#define DETBOX_NMS_CULL(J)                                                                                       \
-    {                                                                                                            \
-        if (lds > 64 * 1024)                                                                                     \
-            DETBOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_segments_cull_kernel<J>),          \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
-        nms_segments_cull_kernel<J><<<grid, dim3(NMS_BLOCK), lds, st>>>(b4, scores, seg_offsets, np, kept_a, kcount, err); \
-    }
-            const int jpt = (int)((max_segment + NMS_BLOCK - 1) / NMS_BLOCK);
-            if (jpt <= 1) DETBOX_NMS_CULL(1)
-            else if (jpt <= 2) DETBOX_NMS_CULL(2)
-            else if (jpt <= 4) DETBOX_NMS_CULL(4)
-            else if (jpt <= 8) DETBOX_NMS_CULL(8)
-            else DETBOX_NMS_CULL(16)
-#undef DETBOX_NMS_CULL
-            if (getenv("DETBOX_NMS_DBG")) {
-                long long h[16];
-                (void)hipDeviceSynchronize();
-                (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_nms_dbg), sizeof(h));
-                fprintf(stderr, "nmsdbg sort %lld gather %lld build %lld mask %lld resolve %lld sweep %lld sweepwait %lld out %lld\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
-                long long z[16] = {0};
-                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nms_dbg), z, sizeof(z));
-            }
-        } else if (fast) {
+        if (fast) {
             const size_t lds = nms_fast_lds(np.max_seg, np.n2).total;
 #define DETBOX_NMS_FAST(J)                                                                                       \
     {                                                                                                            \
