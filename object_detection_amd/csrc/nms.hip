@@ -80,6 +80,65 @@ __device__ inline void bitonic_desc_u64(unsigned long long *s, int n) {
     }
 }
 
+// Bitonic sort (descending) of 256*R keys held R per thread: element e = m*256 + tid lives in K[m] of
+// thread tid.  Strides >= 256 are exchanges between registers of one thread, strides < 64 are wave
+// shuffles; only strides 64 and 128 go through LDS (`xch`, 256*R keys) and need barriers.  Keys at
+// e >= n2 must be zero: only the passes up to n2 run and they never move a key across an n2 boundary.
+template <int R, int KK>
+__device__ inline void bitonic_stage_u64(unsigned long long (&K)[R], unsigned long long *xch, const int tid) {
+#pragma unroll
+    for (int j = KK >> 1; j > 0; j >>= 1) {
+        if (j >= 256) {
+            const int dm = j >> 8;
+#pragma unroll
+            for (int m = 0; m < R; ++m) {
+                const int pm = m ^ dm;
+                if (pm > m) {
+                    const unsigned long long a = K[m], c = K[pm];
+                    const bool desc = ((m * 256) & KK) == 0;           // KK >= 512 here: the bit lies in m
+                    if (desc ? (a < c) : (a > c)) { K[m] = c; K[pm] = a; }
+                }
+            }
+        } else {
+            if (j >= 64) {
+#pragma unroll
+                for (int m = 0; m < R; ++m) xch[m * 256 + tid] = K[m];
+                __syncthreads();
+            }
+#pragma unroll
+            for (int m = 0; m < R; ++m) {
+                const int e = m * 256 + tid;
+                const unsigned long long a = K[m];
+                const unsigned long long c = j >= 64 ? xch[e ^ j] : __shfl_xor(a, j);
+                const bool lower = (tid & j) == 0;
+                const bool desc = (e & KK) == 0;
+                const unsigned long long mx = a > c ? a : c, mn = a > c ? c : a;
+                K[m] = (lower == desc) ? mx : mn;
+            }
+            if (j >= 64) __syncthreads();
+        }
+    }
+}
+
+template <int R, int KK>
+__device__ inline void bitonic_stages_u64(unsigned long long (&K)[R], unsigned long long *xch, const int n2, const int tid) {
+    if constexpr (KK <= 256 * R) {
+        if (KK <= n2) {                                      // uniform over the workgroup
+            bitonic_stage_u64<R, KK>(K, xch, tid);
+            bitonic_stages_u64<R, KK * 2>(K, xch, n2, tid);
+        }
+    }
+}
+
+// Bitonic sort (descending) of 256*R keys held R per thread: element e = m*256 + tid lives in K[m] of
+// thread tid.  Strides >= 256 are exchanges between registers of one thread, strides < 64 are wave
+// shuffles; only strides 64 and 128 go through LDS (`xch`, 256*R keys) and need barriers.  Keys at
+// e >= n2 must be zero: only the stages up to n2 run and they never move a key across an n2 boundary.
+template <int R>
+__device__ inline void bitonic_desc_u64_regs(unsigned long long (&K)[R], unsigned long long *xch, const int n2, const int tid) {
+    bitonic_stages_u64<R, 2>(K, xch, n2, tid);
+}
+
 __device__ inline unsigned long long uniform64(unsigned long long v) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -310,8 +369,9 @@ __host__ __device__ inline NmsFastLds nms_fast_lds(int max_seg, int n2) {
     const size_t words_cap = (size_t)((max_seg + 63) >> 6);
     NmsFastLds l;
     size_t off = 0;
-    l.keys = off;    off += (size_t)n2 * 8;
-    l.box = off;     off += (size_t)max_seg * 16;
+    l.keys = off;                                                     // sort exchange buffer, dead before the boxes arrive
+    const size_t xch = (size_t)(n2 > 256 ? n2 : 256) * 8;
+    l.box = off;     off += (size_t)max_seg * 16 > xch ? (size_t)max_seg * 16 : xch;
     l.kbox = off;    off += 64 * 16;
     l.removed = off; off += ((words_cap * 8 + 15) & ~(size_t)15);
     l.mask = off;    off += 64 * 8;
@@ -321,8 +381,9 @@ __host__ __device__ inline NmsFastLds nms_fast_lds(int max_seg, int n2) {
     return l;
 }
 
+// Five workgroups per CU (five waves per SIMD) keep a whole 80-class x 16-image launch resident in one round.
 template <int JPT>
-__global__ __launch_bounds__(NMS_BLOCK) void nms_segments_fast_kernel(
+__global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <= 4 ? 5 : 1))) void nms_segments_fast_kernel(
     const float4 *__restrict__ boxes, const float *__restrict__ scores, const int32_t *__restrict__ seg_off,
     NmsParams np, float2 *__restrict__ kept, int32_t *__restrict__ kcount, int32_t *__restrict__ err) {
     extern __shared__ unsigned long long s_dyn[];
@@ -360,16 +421,19 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_segments_fast_kernel(
 
     int n2 = 2;
     while (n2 < n) n2 <<= 1;
-    for (int i = tid; i < n2; i += NMS_BLOCK) {
-        unsigned long long k = 0ull;
+    unsigned long long K[JPT];
+#pragma unroll
+    for (int m = 0; m < JPT; ++m) {
+        const int i = tid + m * NMS_BLOCK;
+        K[m] = 0ull;
         if (i < n)   // every real key is above the zero padding: its low word is 0xffffffff - i > 0
-            k = ((unsigned long long)okey_from_bits(__float_as_uint(scores[row0 + i])) << 32) |
-                (unsigned long long)(0xffffffffu - (uint32_t)i);
-        s_keys[i] = k;
+            K[m] = ((unsigned long long)okey_from_bits(__float_as_uint(scores[row0 + i])) << 32) |
+                   (unsigned long long)(0xffffffffu - (uint32_t)i);
     }
-    __syncthreads();
-    bitonic_desc_u64(s_keys, n2);
+    bitonic_desc_u64_regs<JPT>(K, s_keys, n2, tid);
+    __syncthreads();                                     // the exchange buffer overlaps the box array
     // boxes in sorted order: LDS copy for the chunk phases, register copy of the thread's own boxes
+    int orig[JPT];
     float4 bj[JPT];
     float aj[JPT];
     float lx = __builtin_inff(), ly = __builtin_inff(), hx = -__builtin_inff(), hy = -__builtin_inff();
@@ -378,8 +442,10 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_segments_fast_kernel(
         const int j = tid + m * NMS_BLOCK;
         bj[m] = make_float4(0.f, 0.f, 0.f, 0.f);
         aj[m] = 0.f;
+        orig[m] = 0;
         if (j < n) {
-            const int o = (int)(0xffffffffu - (uint32_t)(s_keys[j] & 0xffffffffull));
+            const int o = (int)(0xffffffffu - (uint32_t)(K[m] & 0xffffffffull));
+            orig[m] = o;
             bj[m] = boxes[row0 + o];
             aj[m] = (bj[m].z - bj[m].x) * (bj[m].w - bj[m].y);
             s_box[j] = bj[m];
@@ -539,11 +605,14 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_segments_fast_kernel(
         if (lane == 0) kcount[(size_t)b * np.S + s] = (int32_t)running;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += NMS_BLOCK) {
+#pragma unroll
+    for (int m = 0; m < JPT; ++m) {
+        const int i = tid + m * NMS_BLOCK;
+        if (i >= n) continue;
         const unsigned long long rem = s_removed[i >> 6];
         if ((rem >> (i & 63)) & 1ull) continue;
         const uint32_t rank = s_wprefix[i >> 6] + (uint32_t)__popcll(~rem & ((1ull << (i & 63)) - 1ull));
-        const int pos = seg0 + (int)(0xffffffffu - (uint32_t)(s_keys[i] & 0xffffffffull));
+        const int pos = seg0 + orig[m];
         kept[row0 + rank] = make_float2(scores[(size_t)b * np.stride + pos], __int_as_float(pos));
     }
 }
