@@ -11,9 +11,9 @@
 //                (suppression bitmap in LDS).  Only kept boxes ever act as
 //                suppressors, exactly like the sequential CPU algorithm.
 // nms_scan       per image: offsets of the kept runs.
-// nms_merge      log2(S) stable merge levels (rank by binary search in the sibling
-//                run) turn the per-class kept runs into one list per image in
-//                descending score order -- the order torchvision returns.
+// nms_merge      log2(S) stable merge levels (merge-path tiles staged in LDS) turn the
+//                per-class kept runs into one list per image in descending score order
+//                -- the order torchvision returns.
 //
 // IoU arithmetic follows torchvision's CPU kernel: areas (x2-x1)*(y2-y1),
 // inter / (area_i + area_j - inter) in fp32, suppressed iff (double)iou > threshold;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_segments_generic_kernel(
             unsigned long long k = 0ull;
             if (i < n) {
                 // every real key is above the zero padding: its low word is 0xffffffff - i > 0
-                k = ((unsigned long long)okey_from_bits(__float_as_uint(scores[row0 + i])) << 32) |
+                k = ((unsigned long long)okey_from_bits(__float_as_uint(scores[row0 + i] + 0.0f)) << 32) |
                     (unsigned long long)(0xffffffffu - (uint32_t)i);
             }
             s_keys[i] = k;
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_segments_generic_kernel(
         if ((rem >> (i & 63)) & 1ull) continue;
         const uint32_t rank = s_wprefix[i >> 6] + (uint32_t)__popcll(~rem & ((1ull << (i & 63)) - 1ull));
         const int pos = seg0 + order_of(i);
-        kept[row0 + rank] = make_float2(scores[(size_t)b * np.stride + pos], __int_as_float(pos));
+        kept[row0 + rank] = make_float2(__uint_as_float(okey_from_bits(__float_as_uint(scores[(size_t)b * np.stride + pos] + 0.0f))), __int_as_float(pos));
     }
 }
 
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
         const int i = tid + m * NMS_BLOCK;
         K[m] = 0ull;
         if (i < n)   // every real key is above the zero padding: its low word is 0xffffffff - i > 0
-            K[m] = ((unsigned long long)okey_from_bits(__float_as_uint(scores[row0 + i])) << 32) |
+            K[m] = ((unsigned long long)okey_from_bits(__float_as_uint(scores[row0 + i] + 0.0f)) << 32) |
                    (unsigned long long)(0xffffffffu - (uint32_t)i);
     }
     bitonic_desc_u64_regs<JPT>(K, s_keys, n2, tid);
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
         if ((rem >> (i & 63)) & 1ull) continue;
         const uint32_t rank = s_wprefix[i >> 6] + (uint32_t)__popcll(~rem & ((1ull << (i & 63)) - 1ull));
         const int pos = seg0 + orig[m];
-        kept[row0 + rank] = make_float2(scores[(size_t)b * np.stride + pos], __int_as_float(pos));
+        kept[row0 + rank] = make_float2(__uint_as_float(okey_from_bits(__float_as_uint(scores[(size_t)b * np.stride + pos] + 0.0f))), __int_as_float(pos));
     }
 }
 
@@ -630,42 +630,82 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const int32_t *__restrict
     keep_counts[b] = err[b] ? -1 : acc;
 }
 
-// One stable merge level.  Runs at this level are groups of (1 << level) class segments; element t
-// of image b finds its rank inside the sibling run by binary search on the (descending) scores.
-__global__ __launch_bounds__(256) void nms_merge_kernel(
+// One stable merge level: neighbouring runs (each `group` class segments of one image) are merged
+// pairwise.  A run element is (ordered score key, row index); the left run wins ties, which keeps equal
+// scores in ascending row order.  Every workgroup produces one tile of MP_TILE outputs of one pair: two
+// merge-path searches in global memory bound the tile's inputs, which are staged in LDS; every thread
+// then finds its own starting point by a merge-path search in LDS and merges MP_VT outputs serially.
+constexpr int MP_THREADS = 256;
+constexpr int MP_VT = 8;
+constexpr int MP_TILE = MP_THREADS * MP_VT;
+
+__device__ inline uint32_t run_key(const float2 v) { return __float_as_uint(v.x); }
+
+__global__ __launch_bounds__(MP_THREADS) void nms_merge_kernel(
     const float2 *__restrict__ src, float2 *__restrict__ dst, int64_t *__restrict__ keep_out,
-    const int32_t *__restrict__ koff, const int32_t *__restrict__ seg_off, int S, long long stride, int level,
+    const int32_t *__restrict__ koff, const int32_t *__restrict__ seg_off, int S, long long stride, int group,
     int gapped, int last) {
-    const int b = blockIdx.y;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float2 s_in[MP_TILE];
+    __shared__ int s_split[2];
+    const int b = blockIdx.z, pair = blockIdx.y, tile = blockIdx.x;
     const int32_t *ko = koff + (size_t)b * (S + 1);
-    const int total = ko[S];
-    if (t >= total) return;
-    int lo = 0, hi = S;                          // largest s with ko[s] <= t
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (ko[mid] <= t) lo = mid; else hi = mid;
-    }
-    const int s = lo;
     const int32_t *so = seg_off + (size_t)b * (S + 1);
+    const int sA = pair * 2 * group;
+    if (sA >= S) return;
+    const int sB = min(S, sA + group), sE = min(S, sA + 2 * group);
+    const int nA = ko[sB] - ko[sA], nB = ko[sE] - ko[sB];
+    const int total = nA + nB;
+    const int d0 = tile * MP_TILE;
+    if (d0 >= total) return;
+    const int d1 = min(d0 + MP_TILE, total);
     const size_t base = (size_t)b * stride;
-    const int run = s >> level, sib = run ^ 1;
-    const int own_start = ko[min(S, run << level)];
-    const int sib_lo = ko[min(S, sib << level)], sib_hi = ko[min(S, (sib + 1) << level)];
-    // gapped (level 0 only): run == segment, element r of segment x sits at seg_off[x] + r
-    const int sib_shift = gapped ? (so[min(S, sib)] - sib_lo) : 0;
-    const float2 me = src[base + (gapped ? so[s] + (t - ko[s]) : t)];
-    const bool sib_is_right = (run & 1) == 0;
-    int a = sib_lo, c = sib_hi;                  // first sibling index that does NOT precede me
-    while (a < c) {
-        const int mid = (a + c) >> 1;
-        const float sv = src[base + mid + sib_shift].x;
-        const bool precedes = sib_is_right ? (sv > me.x) : (sv >= me.x);
-        if (precedes) a = mid + 1; else c = mid;
+    // gapped (first level only, group == 1): the kept run of segment x starts at seg_off[x]
+    const float2 *A = src + base + (gapped ? so[sA] : ko[sA]);
+    const float2 *Bp = src + base + (gapped ? so[sB] : ko[sB]);
+    const int tid = threadIdx.x;
+    if (tid < 128) {        // waves 0 and 1: number of left-run elements among the first d0 / d1 outputs
+        const int d = tid >= 64 ? d1 : d0;
+        const int lane = tid & 63;
+        int lo = max(0, d - nB), hi = min(d, nA);
+        // 64-ary search: the predicate "A[p] goes before B[d-1-p]" holds for a prefix of [lo, hi)
+        while (hi - lo > 64) {
+            const int step = (hi - lo + 63) >> 6;
+            const int p = lo + (lane + 1) * step - 1;
+            const bool before = p < hi && run_key(A[p]) >= run_key(Bp[d - 1 - p]);
+            const int c = __popcll(__ballot(before));
+            hi = min(hi, lo + (c + 1) * step - 1);
+            lo = lo + c * step;
+        }
+        const int p = lo + lane;
+        const bool before = p < hi && run_key(A[p]) >= run_key(Bp[d - 1 - p]);
+        lo += __popcll(__ballot(before));
+        if (lane == 0) s_split[tid >> 6] = lo;
     }
-    const int out = min(own_start, sib_lo) + (t - own_start) + (a - sib_lo);
-    if (last) keep_out[base + out] = (int64_t)__float_as_int(me.y);
-    else dst[base + out] = me;
+    __syncthreads();
+    const int a0 = s_split[0], a1 = s_split[1];
+    const int b0 = d0 - a0;
+    const int na = a1 - a0, nb = (d1 - d0) - na;
+    for (int i = tid; i < na; i += MP_THREADS) s_in[i] = A[a0 + i];
+    for (int i = tid; i < nb; i += MP_THREADS) s_in[na + i] = Bp[b0 + i];
+    __syncthreads();
+    const int nt = na + nb;
+    const int t0 = min(tid * MP_VT, nt), t1 = min(t0 + MP_VT, nt);
+    int lo = max(0, t0 - nb), hi = min(t0, na);
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (run_key(s_in[mid]) >= run_key(s_in[na + t0 - 1 - mid])) lo = mid + 1; else hi = mid;
+    }
+    int ia = lo, ib = t0 - lo;
+    const size_t out0 = base + (last ? 0 : ko[sA]) + d0;
+    for (int o = t0; o < t1; ++o) {
+        bool take_a = ib >= nb;
+        if (!take_a && ia < na) take_a = run_key(s_in[ia]) >= run_key(s_in[na + ib]);
+        const float2 v = take_a ? s_in[ia] : s_in[na + ib];
+        ia += take_a ? 1 : 0;
+        ib += take_a ? 0 : 1;
+        if (last) keep_out[out0 + o] = (int64_t)__float_as_int(v.y);
+        else dst[out0 + o] = v;
+    }
 }
 
 __global__ __launch_bounds__(256) void pack_detections_kernel(
@@ -811,18 +851,21 @@ extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scor
         nms_scan_kernel<<<dim3((unsigned)B), dim3(64), 0, st>>>(kcount, (int)S, koff, err, keep_counts);
         DETBOX_LAUNCH_CHECK();
     }
-    int levels = 0;
-    while ((1ll << levels) < S) ++levels;
-    if (levels < 1) levels = 1;
-    dim3 grid((unsigned)((stride + 255) / 256), (unsigned)B);
     float2 *src = kept_a, *dst = kept_b;
-    for (int lv = 0; lv < levels; ++lv) {
+    long long group = 1;
+    do {
+        const long long runs = (S + group - 1) / group;
+        const long long pairs = (runs + 1) / 2;
+        long long longest = 2 * group * max_segment;
+        if (longest > stride) longest = stride;
+        const int last = pairs == 1 ? 1 : 0;
         ProfScope ps("nms_merge", st);
-        nms_merge_kernel<<<grid, dim3(256), 0, st>>>(src, dst, keep, koff, seg_offsets, (int)S, stride, lv,
-                                                     lv == 0 ? 1 : 0, lv == levels - 1 ? 1 : 0);
+        nms_merge_kernel<<<dim3((unsigned)((longest + MP_TILE - 1) / MP_TILE), (unsigned)pairs, (unsigned)B), dim3(MP_THREADS), 0,
+                           st>>>(src, dst, keep, koff, seg_offsets, (int)S, stride, (int)group, group == 1 ? 1 : 0, last);
         DETBOX_LAUNCH_CHECK();
         float2 *tmp = src; src = dst; dst = tmp;
-    }
+        group *= 2;
+    } while (group < S);
     return DETBOX_OK;
 }
 
