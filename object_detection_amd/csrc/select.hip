@@ -402,14 +402,16 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
                                                                  unsigned long long *__restrict__ blk_list,
                                                                  uint32_t *__restrict__ img_ovf) {
     extern __shared__ float s_dynf[];
-    uint32_t *s_n = reinterpret_cast<uint32_t *>(s_dynf + 2 * sp.tile_floats);
     const int b = blockIdx.y, tid = threadIdx.x;
     const int Cs = sp.Cs, cb = sp.cb, C = sp.C;
     const uint32_t key_thr = sp.key_thr;
     const SelRule *rb = rules + (size_t)b * Cs;
     const size_t blk = (size_t)b * gridDim.x + blockIdx.x;
-    unsigned long long *list = blk_list + blk * sp.blk_cap;
-    const uint32_t blk_cap = (uint32_t)sp.blk_cap;
+    // every wave appends to its own quarter of the workgroup's list: no atomics, a wave-uniform count
+    const int wv = tid >> 6;
+    const uint32_t wcap = (uint32_t)sp.blk_cap >> 2;
+    unsigned long long *wlist = blk_list + blk * sp.blk_cap + (size_t)wv * wcap;
+    uint32_t wn = 0;
     // the lane's classes never change: their staging thresholds live in registers
     const int r = tid >> 2, sub = tid & 3;
     float tlo[EPT];
@@ -418,8 +420,6 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
         const int c = sub + 4 * i;
         tlo[i] = (c >= cb && c < C && rb[c - cb].mode == RULE_STAGED) ? rb[c - cb].min_score : __builtin_inff();
     }
-    if (tid == 0) *s_n = 0u;
-    __syncthreads();
 
     const long long sub0 = (long long)blockIdx.x * sp.subs_per_block;
     const long long sub1 = min((long long)sp.n_sub, sub0 + sp.subs_per_block);
@@ -431,23 +431,25 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
 #pragma unroll
                 for (int i = 0; i < EPT; ++i) pm |= (unsigned long long)(x[i] >= tlo[i]) << i;
             }
-            if (pm) {                                   // rare: one reservation per lane, then its few candidates
-                uint32_t slot = atomicAdd(s_n, (uint32_t)__popcll(pm));
-                const uint32_t p = (uint32_t)(r0 + r);
-                do {
+            // round k appends the k-th candidate of every lane that still has one
+            unsigned long long has = __ballot(pm != 0ull);
+            const uint32_t p = (uint32_t)(r0 + r);
+            while (has) {
+                if (pm) {
+                    const uint32_t slot = wn + __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0u));
                     const int i = __ffsll((long long)pm) - 1;
                     pm &= pm - 1ull;
-                    const float sc = rescore<ACT>(ctx, i);           // same arithmetic as x[i], bit for bit
-                    if (slot < blk_cap) list[slot] = pack_entry(okey(sc) - key_thr, (uint32_t)(sub + 4 * i - cb), p);
-                    ++slot;
-                } while (pm);
+                    const float sc = rescore<ACT>(ctx, i);               // same arithmetic as x[i], bit for bit
+                    if (slot < wcap) wlist[slot] = pack_entry(okey(sc) - key_thr, (uint32_t)(sub + 4 * i - cb), p);
+                }
+                wn += (uint32_t)__popcll(has);
+                has = __ballot(pm != 0ull);
             }
         },
         [](long long) {});
-    if (tid == 0) {
-        const uint32_t n = *s_n;                          // behind the loop's last barrier
-        blk_cnt[blk] = n < blk_cap ? n : blk_cap;
-        if (n > blk_cap) img_ovf[b] = 1u;                 // the image falls back to the exact path
+    if ((tid & 63) == 0) {
+        blk_cnt[blk * 4 + wv] = wn < wcap ? wn : wcap;
+        if (wn > wcap) img_ovf[b] = 1u;                   // the image falls back to the exact path
     }
 }
 
@@ -460,13 +462,18 @@ __global__ __launch_bounds__(256) void select_bucket_kernel(SelParams sp, const 
     __shared__ uint32_t s_ccount[MAX_SEL_CLASSES], s_cbase[MAX_SEL_CLASSES];
     const int b = blockIdx.y, tid = threadIdx.x;
     const size_t blk = (size_t)b * gridDim.x + blockIdx.x;
-    const int n = (int)blk_cnt[blk];
-    if (n == 0) return;
+    const int wcap = sp.blk_cap >> 2;
+    int nw[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) nw[w] = (int)blk_cnt[blk * 4 + w];
+    if (nw[0] + nw[1] + nw[2] + nw[3] == 0) return;
     const unsigned long long *list = blk_list + blk * sp.blk_cap;
     const int Cs = sp.Cs, cap = sp.cap;
     if (tid < MAX_SEL_CLASSES) s_ccount[tid] = 0u;
     __syncthreads();
-    for (int e = tid; e < n; e += 256) atomicAdd(&s_ccount[(uint32_t)(list[e] >> 24) & 0xffu], 1u);
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        for (int e = tid; e < nw[w]; e += 256) atomicAdd(&s_ccount[(uint32_t)(list[w * wcap + e] >> 24) & 0xffu], 1u);
     __syncthreads();
     if (tid < Cs) {
         const uint32_t c = s_ccount[tid];
@@ -475,13 +482,16 @@ __global__ __launch_bounds__(256) void select_bucket_kernel(SelParams sp, const 
     }
     __syncthreads();
     unsigned long long *stg = staging + (size_t)b * Cs * cap;
-    for (int e = tid; e < n; e += 256) {
-        const unsigned long long en = list[e];
-        const uint32_t ci = (uint32_t)(en >> 24) & 0xffu;
-        const uint32_t pos = s_cbase[ci] + atomicAdd(&s_ccount[ci], 1u);
-        const uint32_t p = (uint32_t)en & 0xffffffu;
-        if (pos < (uint32_t)cap)
-            stg[(size_t)ci * cap + pos] = (en & 0xffffffff00000000ull) | (unsigned long long)(0xffffffffu - p);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        for (int e = tid; e < nw[w]; e += 256) {
+            const unsigned long long en = list[w * wcap + e];
+            const uint32_t ci = (uint32_t)(en >> 24) & 0xffu;
+            const uint32_t pos = s_cbase[ci] + atomicAdd(&s_ccount[ci], 1u);
+            const uint32_t p = (uint32_t)en & 0xffffffu;
+            if (pos < (uint32_t)cap)
+                stg[(size_t)ci * cap + pos] = (en & 0xffffffff00000000ull) | (unsigned long long)(0xffffffffu - p);
+        }
     }
 }
 
@@ -932,12 +942,36 @@ struct SelPlan {
 // With a 1-in-rate sample, the score whose sample rank is m has, with probability about 1 - 3e-6
 // (z = 4.5 standard deviations of the binomial), at least top_k scores at or above it; `upper` bounds
 // the number of scores at or above it by the same margin on the other side.
-SelPlan make_plan(int64_t B, int64_t P, int64_t Cs, int top_k) {
+int ept_for(int64_t C) { return C <= 32 ? 8 : (C <= 96 ? 24 : (C <= 128 ? 32 : 64)); }
+
+// LDS floats of one sub-tile: the data, the alignment shift, and 4*EPT floats of slack so that the
+// unconditional register loads of compute_subtile stay inside the buffer.
+int tile_floats_for(int64_t C) { return (int)(((SUB_ROWS * C + 4 * ept_for(C) + 8) / 4 + 1) * 4); }
+
+// Workgroups of the scan that are resident at once: LDS-limited, on every CU of the device.
+int64_t scan_resident_workgroups(int64_t C) {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus = n;
+    }
+    const size_t lds = 2 * (size_t)tile_floats_for(C) * 4 + 16;
+    int64_t per_cu = (int64_t)((160 * 1024) / lds);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    return per_cu * cus;
+}
+
+SelPlan make_plan(int64_t B, int64_t P, int64_t C, int64_t Cs, int top_k) {
     SelPlan sp;
     std::memset(&sp, 0, sizeof(sp));
     const double z = 4.5;
     sp.n_sub = (int)((P + SUB_ROWS - 1) / SUB_ROWS);
-    int64_t spb = (B * sp.n_sub + 1023) / 1024;          // about two rounds of resident workgroups
+    // one round of resident workgroups: a second, partly filled round would cost as much as a full one
+    const int64_t resident = scan_resident_workgroups(C);
+    int64_t spb = (B * sp.n_sub + resident - 1) / resident;
     sp.subs_per_block = (int)(spb < 1 ? 1 : spb);
     sp.scan_gx = (sp.n_sub + sp.subs_per_block - 1) / sp.subs_per_block;
     if (P < 4096 || P > (1 << 24)) {                     // tiny inputs, or anchors beyond the 24-bit entry field
@@ -978,7 +1012,7 @@ SelLayout layout(int64_t B, int64_t P, int64_t C, int64_t Cs, const SelPlan &pl,
     L.cnt = off; off = align_up(off + (size_t)B * Cs * sizeof(uint32_t), 256);
     L.flag = off; off = align_up(off + sizeof(uint32_t), 256);
     L.img_ovf = off; off = align_up(off + (size_t)B * sizeof(uint32_t), 256);
-    L.blk_cnt = off; off = align_up(off + (size_t)B * pl.scan_gx * sizeof(uint32_t), 256);
+    L.blk_cnt = off; off = align_up(off + (size_t)B * pl.scan_gx * 4 * sizeof(uint32_t), 256);
     L.zero_bytes = off;                      // histogram, counters and flags are cleared every call
     L.rules = off; off = align_up(off + (size_t)B * Cs * sizeof(SelRule), 256);
     L.staging = off; off = align_up(off + (size_t)B * Cs * pl.cap * sizeof(unsigned long long), 256);
@@ -989,12 +1023,6 @@ SelLayout layout(int64_t B, int64_t P, int64_t C, int64_t Cs, const SelPlan &pl,
     L.total = off;
     return L;
 }
-
-int ept_for(int64_t C) { return C <= 32 ? 8 : (C <= 96 ? 24 : (C <= 128 ? 32 : 64)); }
-
-// LDS floats of one sub-tile: the data, the alignment shift, and 4*EPT floats of slack so that the
-// unconditional register loads of compute_subtile stay inside the buffer.
-int tile_floats_for(int64_t C) { return (int)(((SUB_ROWS * C + 4 * ept_for(C) + 8) / 4 + 1) * 4); }
 
 template <typename K>
 int set_lds(K kernel, size_t lds) {
@@ -1139,7 +1167,7 @@ extern "C" int detbox_activate_scores(int activation, const float *in, const flo
 extern "C" size_t detbox_select_decode_workspace_bytes(int64_t B, int64_t P, int64_t C, int class_begin, int top_k,
                                                        int activation) {
     if (B <= 0 || C <= class_begin || top_k <= 0) return 256;
-    return layout(B, P, C, C - class_begin, make_plan(B, P, C - class_begin, top_k), activation).total;
+    return layout(B, P, C, C - class_begin, make_plan(B, P, C, C - class_begin, top_k), activation).total;
 }
 
 extern "C" int detbox_select_decode(int decode_mode, int activation, const float *scores, const float *extra,
@@ -1179,7 +1207,7 @@ extern "C" int detbox_select_decode(int decode_mode, int activation, const float
                      "scores, locs and out_boxes must be 16-byte aligned");
     DETBOX_CHECK_ARG(decode_mode != DETBOX_DECODE_CXCYWH || (uintptr_t)anchors % 16 == 0, "anchors must be 16-byte aligned");
     DETBOX_CHECK_ARG(decode_mode != DETBOX_DECODE_FCOS || (uintptr_t)anchors % 8 == 0, "points must be 8-byte aligned");
-    const SelPlan plan = make_plan(B, P, Cs, top_k);
+    const SelPlan plan = make_plan(B, P, C, Cs, top_k);
     const int cap = plan.cap;
     const SelLayout L = layout(B, P, C, Cs, plan, activation);
     if (!workspace || (uintptr_t)workspace % 256 || workspace_bytes < L.total) {
