@@ -26,10 +26,20 @@ namespace {
 constexpr int ASSIGN_BLOCK = 256;
 constexpr int GCHUNK = 128;       // GT boxes staged in LDS at a time
 
+// Maximum over the 64 lanes of a wavefront with data-parallel-primitive moves (no LDS traffic):
+// quad swaps, half-row and row mirrors, then the row broadcasts leave the result in lane 63.
+// Every lane of the wave must be active.
 __device__ inline float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+#define DETBOX_DPP_MAX(ctrl, rows)                                                                                  \
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rows, 0xf, false)))
+    DETBOX_DPP_MAX(0xB1, 0xf);      // quad_perm [1,0,3,2]
+    DETBOX_DPP_MAX(0x4E, 0xf);      // quad_perm [2,3,0,1]
+    DETBOX_DPP_MAX(0x141, 0xf);     // row_half_mirror
+    DETBOX_DPP_MAX(0x140, 0xf);     // row_mirror
+    DETBOX_DPP_MAX(0x142, 0xa);     // row_bcast:15 into rows 1 and 3
+    DETBOX_DPP_MAX(0x143, 0xc);     // row_bcast:31 into rows 2 and 3
+#undef DETBOX_DPP_MAX
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 template <int MODE>

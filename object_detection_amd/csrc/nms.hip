@@ -22,6 +22,7 @@
 #include "detbox_internal.h"
 
 #include <cmath>
+#include <type_traits>
 
 using namespace detbox;
 
@@ -315,8 +316,8 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_segments_generic_kernel(
 // resolve over the rows that suppress anything, then the boxes the chunk keeps are broadcast with
 // readlane against every later box still alive (wave-uniform 64-bit alive masks per register slot).
 //
-// The pair test is two-staged.  Stage 1 is a conservative integer reject on boxes quantised to 16 bits
-// over the segment's extent (outer boxes: low edges rounded down, high edges up), two coordinates per
+// The pair test is two-staged.  Stage 1 is a conservative integer reject on quantised boxes
+// over the segment's extent (outer boxes on a 15-bit grid: low edges rounded down, high edges up), two coordinates per
 // packed instruction:  inter_up = w_q * h_q  is an upper bound of the intersection in grid units, and
 //     iou > thr  =>  inter * (1 + thr) > thr * (area_i + area_j)  =>  inter_up > T_i + T_j,
 // T = floor(thr' / (1 + thr') * area * (1 - eps)) per box with thr' a hair below thr; so
@@ -345,25 +346,35 @@ __device__ inline bool suppresses_nodiv(const float4 bi, const float ai, const f
     return it / ((ai + aj) - it) > thr;
 }
 
-// Quantisation of one box: outer box on a 16-bit grid and its threshold share T.
+// Quantisation of one box: outer box on a 15-bit grid and its threshold share T (< 2^29, so that
+// w_q * h_q + (2^30 - T_j) and T_i + 2^30 both stay below 2^31).
 struct QBox { uint32_t lo, hi, T; };
+constexpr uint32_t Q_BIAS = 1u << 30;
+constexpr float Q_MAX = 32767.0f;
+
+// inter_up + (2^30 - T_j):  d = (h_q << 16) | w_q, one multiply-add on the two halves of d
+__device__ inline uint32_t inter_up_biased(uint32_t d, uint32_t bias_minus_t) {
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, %1, %2 op_sel:[0,1,0,0]" : "=v"(r) : "v"(d), "v"(bias_minus_t));
+    return r;
+}
 
 __device__ inline QBox quantise_box(const float4 bx, const float area, const float x0, const float y0, const float scale,
                                     const float t_scale, const bool ok) {
     QBox q;
-    if (!ok) { q.lo = 0u; q.hi = 0xffffffffu; q.T = 0u; return q; }        // never rejects anything
+    if (!ok) { q.lo = 0u; q.hi = 0x7fff7fffu; q.T = 0u; return q; }        // never rejects anything
     const float fx1 = floorf((bx.x - x0) * scale - 0.0625f), fy1 = floorf((bx.y - y0) * scale - 0.0625f);
     const float fx2 = ceilf((bx.z - x0) * scale + 0.0625f), fy2 = ceilf((bx.w - y0) * scale + 0.0625f);
-    const uint32_t x1 = (uint32_t)fminf(fmaxf(fx1, 0.0f), 65535.0f), y1 = (uint32_t)fminf(fmaxf(fy1, 0.0f), 65535.0f);
-    const uint32_t x2 = (uint32_t)fminf(fmaxf(fx2, 0.0f), 65535.0f), y2 = (uint32_t)fminf(fmaxf(fy2, 0.0f), 65535.0f);
+    const uint32_t x1 = (uint32_t)fminf(fmaxf(fx1, 0.0f), Q_MAX), y1 = (uint32_t)fminf(fmaxf(fy1, 0.0f), Q_MAX);
+    const uint32_t x2 = (uint32_t)fminf(fmaxf(fx2, 0.0f), Q_MAX), y2 = (uint32_t)fminf(fmaxf(fy2, 0.0f), Q_MAX);
     q.lo = (y1 << 16) | x1;
     q.hi = (y2 << 16) | x2;
     const float t = area * t_scale;                                         // NaN or <= 0 -> 0
-    q.T = t > 0.0f ? (uint32_t)fminf(t, 2147483648.0f) : 0u;
+    q.T = t > 0.0f ? (uint32_t)fminf(t, 536870848.0f) : 0u;
     return q;
 }
 
-struct NmsFastLds { size_t keys, box, kbox, removed, mask, misc, wprefix, total; };
+struct NmsFastLds { size_t keys, box, qbox, qt, kbox, removed, mask, misc, wprefix, total; };
 
 __host__ __device__ inline NmsFastLds nms_fast_lds(int max_seg, int n2) {
     const size_t words_cap = (size_t)((max_seg + 63) >> 6);
@@ -372,6 +383,8 @@ __host__ __device__ inline NmsFastLds nms_fast_lds(int max_seg, int n2) {
     l.keys = off;                                                     // sort exchange buffer, dead before the boxes arrive
     const size_t xch = (size_t)(n2 > 256 ? n2 : 256) * 8;
     l.box = off;     off += (size_t)max_seg * 16 > xch ? (size_t)max_seg * 16 : xch;
+    l.qbox = off;    off += (size_t)max_seg * 8;                       // quantised outer boxes (lo, hi)
+    l.qt = off;      off += (((size_t)max_seg * 4 + 15) & ~(size_t)15); // threshold shares
     l.kbox = off;    off += 64 * 16;
     l.removed = off; off += ((words_cap * 8 + 15) & ~(size_t)15);
     l.mask = off;    off += 64 * 8;
@@ -401,6 +414,8 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
     char *lds_base = reinterpret_cast<char *>(s_dyn);
     unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(lds_base + ld.keys);
     float4 *s_box = reinterpret_cast<float4 *>(lds_base + ld.box);
+    uint2 *s_qbox = reinterpret_cast<uint2 *>(lds_base + ld.qbox);
+    uint32_t *s_qt = reinterpret_cast<uint32_t *>(lds_base + ld.qt);
     float4 *s_kbox = reinterpret_cast<float4 *>(lds_base + ld.kbox);
     unsigned long long *s_removed = reinterpret_cast<unsigned long long *>(lds_base + ld.removed);
     unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(lds_base + ld.mask);
@@ -469,15 +484,18 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
     // extent is not a sane positive number
     const float E = fmaxf(hx - lx, hy - ly);
     const bool q_ok = E > 1e-30f && E < 1e30f;
-    const float scale = q_ok ? 65535.0f / E : 0.0f;
+    const float scale = q_ok ? Q_MAX / E : 0.0f;
     const float thr_q = fminf(thr * 0.9999f, 1.0f);
     const float t_scale = (thr_q / (1.0f + thr_q)) * scale * scale * 0.9999f;
-    uint32_t qlo[JPT], qhi[JPT], qT[JPT];
+    uint32_t qlo[JPT], qhi[JPT], qTn[JPT];               // qTn = 2^30 - T
 #pragma unroll
     for (int m = 0; m < JPT; ++m) {
         const QBox q = quantise_box(bj[m], aj[m], lx, ly, scale, t_scale, q_ok);
-        qlo[m] = q.lo; qhi[m] = q.hi; qT[m] = q.T;
+        qlo[m] = q.lo; qhi[m] = q.hi; qTn[m] = Q_BIAS - q.T;
+        const int j = tid + m * NMS_BLOCK;
+        if (j < n) { s_qbox[j] = make_uint2(q.lo, q.hi); s_qt[j] = q.T; }
     }
+    __syncthreads();
 
     unsigned rem_mask = 0u;                               // bit m: own box m is suppressed
     for (int ch = 0; ch < words; ++ch) {
@@ -492,9 +510,14 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
                 const int i = first ? rp : 63 - rp;
                 const int j = first ? rp + 1 + c : c + 1;
                 if (j < cn && ((alive0 >> i) & 1ull) && ((alive0 >> j) & 1ull)) {
-                    const float4 bi = s_box[c0 + i];
-                    const float ai = (bi.z - bi.x) * (bi.w - bi.y);
-                    if (suppresses_nodiv(bi, ai, s_box[c0 + j], thr, k_hi, k_lo, u_min)) atomicOr(&s_mask[i], 1ull << j);
+                    const uint2 qi = s_qbox[c0 + i], qj = s_qbox[c0 + j];
+                    const u16x2 d = __builtin_elementwise_sub_sat(__builtin_elementwise_min(as_u16x2(qi.y), as_u16x2(qj.y)),
+                                                                  __builtin_elementwise_max(as_u16x2(qi.x), as_u16x2(qj.x)));
+                    if ((uint32_t)d.x * (uint32_t)d.y > s_qt[c0 + i] + s_qt[c0 + j]) {      // not rejected: the exact test
+                        const float4 bi = s_box[c0 + i];
+                        const float ai = (bi.z - bi.x) * (bi.w - bi.y);
+                        if (suppresses_nodiv(bi, ai, s_box[c0 + j], thr, k_hi, k_lo, u_min)) atomicOr(&s_mask[i], 1ull << j);
+                    }
                 }
             }
         }
@@ -531,21 +554,30 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
                 const float4 kb = lane < nk ? s_kbox[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float ka = (kb.z - kb.x) * (kb.w - kb.y);
                 const QBox kq = quantise_box(kb, ka, lx, ly, scale, t_scale, q_ok);
+                const uint32_t kq_tb = kq.T + Q_BIAS;
                 unsigned long long hit[JPT];
 #pragma unroll
                 for (int m = 0; m < JPT; ++m) hit[m] = 0ull;
-                for (int t = 0; t < nk; ++t) {
-                    const uint32_t klo = __builtin_amdgcn_readlane(kq.lo, t), khi = __builtin_amdgcn_readlane(kq.hi, t);
-                    const uint32_t kT = __builtin_amdgcn_readlane(kq.T, t);
+                // Slots below the first live one lie entirely before the chunk; the sweep is compiled for every
+                // possible first slot (in steps of GS), so no slot is visited just to find its mask empty.
+                constexpr int GS = JPT > 4 ? JPT / 4 : 1;
+                int m_first = 0;
 #pragma unroll
-                    for (int m = 0; m < JPT; ++m) {
-                        if (act[m]) {                                   // wave-uniform
+                for (int m = JPT - 1; m >= 0; --m)
+                    if (act[m]) m_first = m;
+                auto sweep = [&](auto first_slot) {
+                    constexpr int M0 = decltype(first_slot)::value;
+                    for (int t = 0; t < nk; ++t) {
+                        const uint32_t klo = __builtin_amdgcn_readlane(kq.lo, t), khi = __builtin_amdgcn_readlane(kq.hi, t);
+                        const uint32_t ktb = __builtin_amdgcn_readlane(kq_tb, t);
+#pragma unroll
+                        for (int m = M0; m < JPT; ++m) {
+                            if (GS > 1 && !act[m]) continue;                // wave-uniform
                             // stage 1: integer upper bound of the intersection against the threshold shares
                             const u16x2 lo = __builtin_elementwise_max(as_u16x2(klo), as_u16x2(qlo[m]));
                             const u16x2 hi = __builtin_elementwise_min(as_u16x2(khi), as_u16x2(qhi[m]));
-                            const u16x2 d = __builtin_elementwise_sub_sat(hi, lo);
-                            const uint32_t inter_up = (uint32_t)d.x * (uint32_t)d.y;
-                            const unsigned long long open = act[m] & ~__ballot(inter_up <= kT + qT[m]);
+                            const uint32_t d = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(hi, lo));
+                            const unsigned long long open = act[m] & ~__ballot(inter_up_biased(d, qTn[m]) <= ktb);
                             if (open) {                                  // stage 2: the reference's arithmetic
                                 const float ix1 = readlane_f(kb.x, t), iy1 = readlane_f(kb.y, t);
                                 const float ix2 = readlane_f(kb.z, t), iy2 = readlane_f(kb.w, t);
@@ -569,6 +601,12 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
                             }
                         }
                     }
+                };
+                switch (m_first / GS) {
+                    case 0: sweep(std::integral_constant<int, 0>{}); break;
+                    case 1: sweep(std::integral_constant<int, (JPT > 1 ? GS : 0)>{}); break;
+                    case 2: sweep(std::integral_constant<int, (JPT > 2 ? 2 * GS : 0)>{}); break;
+                    default: sweep(std::integral_constant<int, (JPT > 3 ? 3 * GS : 0)>{}); break;
                 }
 #pragma unroll
                 for (int m = 0; m < JPT; ++m) {
@@ -715,6 +753,7 @@ __global__ __launch_bounds__(256) void pack_detections_kernel(
     int64_t *__restrict__ rows_ids, double *__restrict__ rows_vals, int32_t *__restrict__ row_offsets) {
     __shared__ int s_red[256];
     const int b = blockIdx.y;
+    if (blockIdx.x != 0 && (int)(blockIdx.x * blockDim.x) >= keep_counts[b]) return;     // no rows here
     int acc = 0;
     for (int i = threadIdx.x; i < b; i += blockDim.x) acc += max(keep_counts[i], 0);
     s_red[threadIdx.x] = acc;
@@ -729,20 +768,31 @@ __global__ __launch_bounds__(256) void pack_detections_kernel(
         row_offsets[b] = row0;
         if (b == B - 1) row_offsets[B] = row0 + n;
     }
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const size_t base = (size_t)b * stride;
-    const int64_t k = keep[base + t];
-    const float4 bx = boxes[base + k];
-    const double W = (double)image_sizes[2 * b + 1], H = (double)image_sizes[2 * b];
-    const size_t r = (size_t)row0 + t;
-    rows_ids[2 * r] = image_ids[b];
-    rows_ids[2 * r + 1] = cls[base + k];
-    rows_vals[5 * r + 0] = (double)bx.x * W;
-    rows_vals[5 * r + 1] = (double)bx.y * H;
-    rows_vals[5 * r + 2] = (double)(bx.z - bx.x) * W;
-    rows_vals[5 * r + 3] = (double)(bx.w - bx.y) * H;
-    rows_vals[5 * r + 4] = (double)scores[base + k];
+    // rows of this block are built in LDS and leave as contiguous 8-byte streams
+    __shared__ double s_vals[256 * 5];
+    __shared__ int64_t s_ids[256 * 2];
+    const int t0 = blockIdx.x * blockDim.x;
+    if (t0 >= n) return;
+    const int nb = min(256, n - t0);
+    const int t = t0 + threadIdx.x;
+    if (t < n) {
+        const size_t base = (size_t)b * stride;
+        const int64_t k = keep[base + t];
+        const float4 bx = boxes[base + k];
+        const double W = (double)image_sizes[2 * b + 1], H = (double)image_sizes[2 * b];
+        const int r = threadIdx.x;
+        s_ids[2 * r] = image_ids[b];
+        s_ids[2 * r + 1] = cls[base + k];
+        s_vals[5 * r + 0] = (double)bx.x * W;
+        s_vals[5 * r + 1] = (double)bx.y * H;
+        s_vals[5 * r + 2] = (double)(bx.z - bx.x) * W;
+        s_vals[5 * r + 3] = (double)(bx.w - bx.y) * H;
+        s_vals[5 * r + 4] = (double)scores[base + k];
+    }
+    __syncthreads();
+    const size_t r0 = (size_t)row0 + t0;
+    for (int i = threadIdx.x; i < 5 * nb; i += 256) rows_vals[5 * r0 + i] = s_vals[i];
+    for (int i = threadIdx.x; i < 2 * nb; i += 256) rows_ids[2 * r0 + i] = s_ids[i];
 }
 
 struct NmsLayout { size_t kept_a, kept_b, kcount, koff, err, total, zero_off, zero_bytes; };
