@@ -570,14 +570,22 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
                     for (int t = 0; t < nk; ++t) {
                         const uint32_t klo = __builtin_amdgcn_readlane(kq.lo, t), khi = __builtin_amdgcn_readlane(kq.hi, t);
                         const uint32_t ktb = __builtin_amdgcn_readlane(kq_tb, t);
+                        // stage 1 for every live slot first (independent chains, one branch for all of them):
+                        // integer upper bound of the intersection against the threshold shares
+                        unsigned long long open_m[JPT];
+                        unsigned long long any_open = 0ull;
 #pragma unroll
                         for (int m = M0; m < JPT; ++m) {
-                            if (GS > 1 && !act[m]) continue;                // wave-uniform
-                            // stage 1: integer upper bound of the intersection against the threshold shares
                             const u16x2 lo = __builtin_elementwise_max(as_u16x2(klo), as_u16x2(qlo[m]));
                             const u16x2 hi = __builtin_elementwise_min(as_u16x2(khi), as_u16x2(qhi[m]));
                             const uint32_t d = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(hi, lo));
-                            const unsigned long long open = act[m] & ~__ballot(inter_up_biased(d, qTn[m]) <= ktb);
+                            open_m[m] = act[m] & ~__ballot(inter_up_biased(d, qTn[m]) <= ktb);
+                            any_open |= open_m[m];
+                        }
+                        if (!any_open) continue;
+#pragma unroll
+                        for (int m = M0; m < JPT; ++m) {
+                            const unsigned long long open = open_m[m];
                             if (open) {                                  // stage 2: the reference's arithmetic
                                 const float ix1 = readlane_f(kb.x, t), iy1 = readlane_f(kb.y, t);
                                 const float ix2 = readlane_f(kb.z, t), iy2 = readlane_f(kb.w, t);
@@ -746,6 +754,76 @@ __global__ __launch_bounds__(MP_THREADS) void nms_merge_kernel(
     }
 }
 
+// The first merge levels in one launch: a workgroup loads the kept runs of F consecutive class segments
+// of one image (F a power of two, F * max_segment elements fit the LDS buffer), merges them pairwise
+// log2(F) times between two LDS buffers -- every thread produces a contiguous slice of the output by a
+// merge-path search and a serial merge -- and writes one dense run (or, if F covers all segments, the
+// final keep list).
+constexpr int ML_THREADS = 1024;
+constexpr int ML_CAP = 8192;               // elements per LDS buffer (two buffers of 64 KiB)
+
+__global__ __launch_bounds__(ML_THREADS) void nms_merge_lds_kernel(
+    const float2 *__restrict__ src, float2 *__restrict__ dst, int64_t *__restrict__ keep_out,
+    const int32_t *__restrict__ koff, const int32_t *__restrict__ seg_off, int S, long long stride, int F, int last) {
+    extern __shared__ float2 s_ml[];
+    __shared__ int s_off[65];                // run boundaries inside the buffer (F <= 64)
+    float2 *cur = s_ml, *nxt = s_ml + ML_CAP;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int s0 = blockIdx.x * F;
+    if (s0 >= S) return;
+    const int s1 = min(S, s0 + F);
+    const int32_t *ko = koff + (size_t)b * (S + 1);
+    const int32_t *so = seg_off + (size_t)b * (S + 1);
+    const size_t base = (size_t)b * stride;
+    const int out0 = ko[s0];
+    const int total = ko[s1] - out0;
+    __shared__ int s_src[64];                // where run r starts in src, minus its offset in the buffer
+    if (tid <= F) s_off[tid] = ko[min(s1, s0 + tid)] - out0;
+    if (tid < F) s_src[tid] = so[min(S, s0 + tid)] - (ko[min(s1, s0 + tid)] - out0);
+    __syncthreads();
+    for (int e = tid; e < total; e += ML_THREADS) {      // independent loads: the runs sit at their segment starts
+        int r = 0;
+        while (s_off[r + 1] <= e) ++r;
+        cur[e] = src[base + s_src[r] + e];
+    }
+    __syncthreads();
+    const int per = (total + ML_THREADS - 1) / ML_THREADS;
+    for (int g = 1; g < F; g <<= 1) {         // runs of g segments -> runs of 2g segments
+        int o = min(tid * per, total);
+        const int o_end = min(o + per, total);
+        while (o < o_end) {
+            int pr = 0;                        // pair containing output position o
+            while (s_off[min(F, (pr + 1) * 2 * g)] <= o) ++pr;
+            const int a_lo = s_off[min(F, pr * 2 * g)], a_hi = s_off[min(F, pr * 2 * g + g)];
+            const int b_hi = s_off[min(F, (pr + 1) * 2 * g)];
+            const int na = a_hi - a_lo, nb = b_hi - a_hi;
+            const float2 *A = cur + a_lo, *Bp = cur + a_hi;
+            const int d = o - a_lo;            // diagonal inside the pair
+            int lo = max(0, d - nb), hi = min(d, na);
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (run_key(A[mid]) >= run_key(Bp[d - 1 - mid])) lo = mid + 1; else hi = mid;
+            }
+            int ia = lo, ib = d - lo;
+            const int stop = min(o_end, b_hi);
+            for (; o < stop; ++o) {
+                bool take_a = ib >= nb;
+                if (!take_a && ia < na) take_a = run_key(A[ia]) >= run_key(Bp[ib]);
+                nxt[o] = take_a ? A[ia] : Bp[ib];
+                ia += take_a ? 1 : 0;
+                ib += take_a ? 0 : 1;
+            }
+        }
+        __syncthreads();
+        float2 *tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (last) {
+        for (int i = tid; i < total; i += ML_THREADS) keep_out[base + i] = (int64_t)__float_as_int(cur[i].y);
+    } else {
+        for (int i = tid; i < total; i += ML_THREADS) dst[base + out0 + i] = cur[i];
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_detections_kernel(
     const float4 *__restrict__ boxes, const float *__restrict__ scores, const int64_t *__restrict__ cls,
     const int64_t *__restrict__ keep, const int32_t *__restrict__ keep_counts,
@@ -903,7 +981,23 @@ extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scor
     }
     float2 *src = kept_a, *dst = kept_b;
     long long group = 1;
-    do {
+    {   // as many levels as fit in LDS at once
+        long long F = 1;
+        while (F * 2 * max_segment <= ML_CAP && F < 64 && F < S) F *= 2;
+        if (F > 1) {
+            const int last = F >= S ? 1 : 0;
+            const size_t lds = 2 * (size_t)ML_CAP * sizeof(float2);
+            DETBOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_merge_lds_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ProfScope ps("nms_merge", st);
+            nms_merge_lds_kernel<<<dim3((unsigned)((S + F - 1) / F), (unsigned)B), dim3(ML_THREADS), lds, st>>>(
+                src, dst, keep, koff, seg_offsets, (int)S, stride, (int)F, last);
+            DETBOX_LAUNCH_CHECK();
+            float2 *tmp = src; src = dst; dst = tmp;
+            group = F;
+        }
+    }
+    while (group < S || group == 1) {
         const long long runs = (S + group - 1) / group;
         const long long pairs = (runs + 1) / 2;
         long long longest = 2 * group * max_segment;
@@ -915,7 +1009,7 @@ extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scor
         DETBOX_LAUNCH_CHECK();
         float2 *tmp = src; src = dst; dst = tmp;
         group *= 2;
-    } while (group < S);
+    }
     return DETBOX_OK;
 }
 
