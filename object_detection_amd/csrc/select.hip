@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void select_plan_kernel(const float *__restric
                                                           SelRule *__restrict__ rules, uint32_t *__restrict__ flag) {
     extern __shared__ uint32_t s_key[];              // [ns_cap] keys of the sampled scores above the threshold (0 = none)
     __shared__ uint32_t s_h[256];
-    __shared__ uint32_t s_pref, s_rem, s_total;
+    __shared__ uint32_t s_pref, s_rem, s_total, s_max;
     const int ci = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     SelRule r;
     r.pad = 0; r.cutoff = 0ull; r.n_above = 0; r.n_sel = 0;
@@ -345,10 +345,10 @@ __global__ __launch_bounds__(256) void select_plan_kernel(const float *__restric
         if (tid == 0) rules[(size_t)b * sp.Cs + ci] = r;
         return;
     }
-    if (tid == 0) { s_total = 0u; s_pref = 0u; s_rem = (uint32_t)sp.sample_m; }
+    if (tid == 0) { s_total = 0u; s_pref = 0u; s_rem = (uint32_t)sp.sample_m; s_max = 0u; }
     __syncthreads();
     const float *sv = samp + ((size_t)b * sp.Cs + ci) * sp.ns_cap;
-    uint32_t mine = 0;
+    uint32_t mine = 0, kmax = 0;
     for (int i = tid; i < sp.ns_cap; i += 256) {
         const long long row = (long long)(i / SUB_ROWS) * sp.sample_rate * SUB_ROWS + (i % SUB_ROWS);
         uint32_t k = 0u;
@@ -357,19 +357,24 @@ __global__ __launch_bounds__(256) void select_plan_kernel(const float *__restric
             if (v > sp.thr) { k = okey(v) - sp.key_thr; ++mine; }     // k >= 1
         }
         s_key[i] = k;
+        kmax = max(kmax, k);
     }
-    if (mine) atomicAdd(&s_total, mine);
+    if (mine) { atomicAdd(&s_total, mine); atomicMax(&s_max, kmax); }
     __syncthreads();
     r.mode = RULE_STAGED;
     unsigned long long dmin = 1ull;
     if (s_total > (uint32_t)sp.sample_m) {              // block-uniform
-        for (int shift = 24; shift >= 0; shift -= 8) {
+        // radix search from the highest bit any key has, eight bits a round
+        int width = 32 - __clz((int)s_max);            // s_max >= 1 here
+        while (width > 0) {
+            const int bits = width < 8 ? width : 8;
+            const int shift = width - bits;
             const uint32_t pref = s_pref;
             s_h[tid] = 0u;
             __syncthreads();
             for (int i = tid; i < sp.ns_cap; i += 256) {
                 const uint32_t k = s_key[i];
-                if (k && (shift == 24 || (k >> (shift + 8)) == (pref >> (shift + 8)))) atomicAdd(&s_h[(k >> shift) & 255u], 1u);
+                if (k && (width == 32 || (k >> width) == (pref >> width))) atomicAdd(&s_h[(k >> shift) & ((1u << bits) - 1u)], 1u);
             }
             __syncthreads();
             if (tid < 64) {
@@ -381,6 +386,7 @@ __global__ __launch_bounds__(256) void select_plan_kernel(const float *__restric
                 if (lane == 0) { s_pref = pref | (digit << shift); s_rem -= above; }
             }
             __syncthreads();
+            width = shift;
         }
         dmin = s_pref;
     }
