@@ -42,8 +42,8 @@ def _stream(device) -> int:
 
 
 def _workspace(device, nbytes: int, tag: str) -> torch.Tensor:
-    """Grow-only scratch buffer per (device, operator); calls sharing it are ordered on the current stream."""
-    key = (device.index, tag)
+    """Grow-only scratch buffer per (device, operator, stream): calls that share one are ordered on that stream."""
+    key = (device.index, tag, _stream(device))
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
