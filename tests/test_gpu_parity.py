@@ -425,6 +425,60 @@ def test_batched_nms_generic_bit_exact(D, oracle, dev):
     assert got.device.type == 'cpu' and torch.equal(got, O.batched_nms(boxes, scores, idxs, 0.45))
 
 
+def test_nms_adversarial_geometry(D, oracle, dev):
+    """Inputs aimed at the NMS kernel's integer reject stage and its division-free test: pairs whose IoU
+    sits within a few ulps of the threshold, coordinates far from the origin, tiny and huge boxes in
+    one segment, boxes smaller than one quantisation step, nested boxes, every chunk boundary."""
+    O = oracle
+    g = torch.Generator().manual_seed(77)
+
+    def near_threshold_pairs(n_pairs, thr):
+        c = 0.2 + 0.6 * torch.rand(n_pairs, 2, generator=g)
+        wh = 0.05 + 0.2 * torch.rand(n_pairs, 2, generator=g)
+        a = torch.cat([c - wh / 2, c + wh / 2], 1)
+        t = (1 - thr) / (1 + thr) if thr < 1 else 0.0      # x-shift (in widths) that gives IoU == thr
+        jitter = (torch.rand(n_pairs, generator=g) - 0.5) * 4e-6
+        b = a.clone()
+        b[:, 0] += (t + jitter) * wh[:, 0]
+        b[:, 2] += (t + jitter) * wh[:, 0]
+        return torch.cat([a, b], 0)
+
+    cases = []
+    for thr in (0.0, 0.3, 0.45, 0.7, 0.999999, 1.0):
+        cases.append(('near-thr', near_threshold_pairs(700, min(thr, 0.95)), thr))
+    base = rand_boxes(g, 1500, spread=0.8, size=0.15)
+    cases.append(('far-origin', base * 100.0 + 1.0e6, 0.45))
+    cases.append(('tiny', base * 1e-6, 0.45))
+    cases.append(('huge', base * 1e12, 0.45))
+    mixed = base.clone()
+    mixed[0] = torch.tensor([-50.0, -50.0, 50.0, 50.0])                       # one giant box stretches the grid
+    mixed[1:400] = torch.cat([0.3 + 1e-4 * torch.rand(399, 2, generator=g)] * 2, 1) + torch.tensor([0., 0., 2e-5, 2e-5])
+    cases.append(('giant+sub-step', mixed, 0.45))
+    k = torch.arange(1, 1201, dtype=torch.float32)
+    nested = torch.stack([0.5 - 0.0004 * k, 0.5 - 0.0003 * k, 0.5 + 0.0004 * k, 0.5 + 0.0003 * k], 1)
+    cases.append(('nested', nested, 0.45))
+    cases.append(('nested-hi', nested, 0.98))
+    cases.append(('identical', base[:1].repeat(900, 1), 0.45))
+    for n in (2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 4095, 4096):
+        cases.append((f'n={n}', rand_boxes(g, n, spread=0.5, size=0.2), 0.45))
+    for name, boxes, thr in cases:
+        n = boxes.shape[0]
+        scores = torch.rand(n, generator=g)
+        scores[::7] = scores[min(3, n - 1)]                                   # ties
+        idxs = torch.zeros(n, dtype=torch.long)
+        want = O.batched_nms(boxes, scores, idxs, thr)
+        got = D.batched_nms(boxes.to(dev), scores.to(dev), idxs.to(dev), thr)
+        assert torch.equal(got.cpu(), want), (name, thr, n, int(want.numel()), int(got.numel()))
+    # several classes so that every merge arrangement runs: S = 1, 2, 3, 5, 8, 9, 17, 80 segments
+    for ncls in (1, 2, 3, 5, 8, 9, 17, 80):
+        n = 150 * ncls
+        boxes, scores = rand_boxes(g, n, spread=0.7, size=0.2), (torch.rand(n, generator=g) * 40).round() / 40
+        idxs = torch.randint(0, ncls, (n,), generator=g)
+        want = O.batched_nms(boxes, scores, idxs, 0.45)
+        got = D.batched_nms(boxes.to(dev), scores.to(dev), idxs.to(dev), 0.45)
+        assert torch.equal(got.cpu(), want), ncls
+
+
 def test_predictor_run_generic_inputs(D, oracle, dev):
     """Ungrouped class ids take the per-image path; grouped ones the batched path; same dicts."""
     O = oracle
