@@ -98,6 +98,13 @@ int detbox_assign_fcos(const float *points, const float *regress_ranges, int64_t
                        float *target_locs, float *target_cents, int64_t *target_labels, int64_t *matched,
                        void *stream);
 
+/* Hard-negative mining rank mask.  Replaces `loss_neg.argsort(descending=True).argsort() < 3 * num_pos`
+ * of src/models/ssd300.py:277-278 (ssd512 inherits it): out_mask[b,p] = 1 iff the descending rank of
+ * values[b,p] inside row b is below k[b]; equal values rank by ascending index (the reference's sort
+ * leaves that order unspecified); NaN ranks first, -0 equals +0.  values [B,P], k [B], out_mask [B,P]
+ * bytes (0 / 1).  k[b] <= 0 selects nothing, k[b] >= P everything. */
+int detbox_topk_mask(const float *values, const int64_t *k, int64_t B, int64_t P, uint8_t *out_mask, void *stream);
+
 /* ---- inference: activation + threshold + exact top-k + decode ---------------------------- */
 
 /* activations applied to the head output before the threshold */
@@ -177,7 +184,7 @@ int detbox_pack_detections(const float *boxes, const float *scores, const int64_
  * "box_iou", "assign_anchor", "assign_fixup", "assign_fcos", "activate_scores", "select_sample",
  * "select_plan", "select_scan", "select_bucket", "select_check", "select_materialize", "score_hist", "select_kth",
  * "select_refine", "select_emit", "select_finalize", "nms_segments", "nms_scan", "nms_merge",
- * "nms_write", "pack_detections". */
+ * "nms_write", "pack_detections", "topk_mask". */
 int detbox_profile_enable(int on);
 /* Restricts the timing to the one kernel called `name` (NULL or "" = every kernel again), so that a
  * timed run pays the event overhead for that kernel only. */

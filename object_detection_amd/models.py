@@ -127,8 +127,7 @@ class SSD300(_BoxOps):
         pos_mask = target_labels > 0
         loss_neg = F.cross_entropy(out_confs.view(-1, C), target_labels.view(-1), reduction='none').view(B, -1)
         loss_neg[pos_mask] = 0
-        loss_neg_rank = loss_neg.argsort(descending=True).argsort()
-        neg_mask = loss_neg_rank < 3 * pos_mask.sum(dim=1, keepdims=True)
+        neg_mask = ops.topk_mask(loss_neg, 3 * pos_mask.sum(dim=1))      # hard-negative mining, ssd300.py:277-278
         N = pos_mask.sum()
         loss_loc = F.smooth_l1_loss(out_locs[pos_mask], target_locs[pos_mask], reduction='sum') / N
         sel = pos_mask + neg_mask

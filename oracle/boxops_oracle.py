@@ -591,3 +591,11 @@ def synth_gt(i: int, num_fg_classes: int, coco_like: bool, fmt: str = 'cxcywh', 
     if fmt == 'xywh':
         boxes = torch.cat([c - wh / 2, wh], dim=1)
     return boxes * scale, labels
+
+
+def hard_negative_mask(loss_neg: torch.Tensor, num_pos: torch.Tensor) -> torch.Tensor:
+    """src/models/ssd300.py:277-278: `loss_neg.argsort(descending=True).argsort() < 3 * num_pos`.
+    The reference's sort is not stable, so its choice among equal losses at the boundary is unspecified;
+    here (and in the build) the lower index wins."""
+    rank = loss_neg.argsort(dim=1, descending=True, stable=True).argsort(dim=1)
+    return rank < (3 * num_pos).reshape(-1, 1)

@@ -497,6 +497,50 @@ def test_predictor_run_generic_inputs(D, oracle, dev):
         assert got == want
 
 
+def test_topk_mask_hard_negative_mining(D, oracle, dev):
+    """Rank mask of SSD's hard-negative mining against the reference's own neg_mask (golden) and, with
+    ties and edge counts, against the oracle's stable restatement."""
+    import numpy as np
+    import os
+    O = oracle
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'hardneg_ssd300.npz'))
+    loss_neg = torch.from_numpy(d['loss_neg'])
+    want = torch.from_numpy(np.unpackbits(d['neg_mask'], axis=1)[:, :loss_neg.shape[1]]).bool()
+    got = D.ops.topk_mask(loss_neg.to(dev), torch.from_numpy(d['k']).to(dev))
+    assert got.dtype == torch.bool and torch.equal(got.cpu(), want)
+    g = torch.Generator().manual_seed(5)
+    for B, P in ((1, 1), (3, 7), (5, 1000), (4, 1024), (2, 1025), (8, 8732), (2, 24564), (1, 200000)):
+        v = torch.randn(B, P, generator=g)
+        v = (v * 4).round() / 4                                   # heavy ties
+        v[0, : P // 2] = 0.0                                      # a run of equal values across the boundary
+        if P > 4:
+            v[-1, 1], v[-1, 3] = -0.0, 0.0
+        num_pos = torch.randint(0, max(1, P // 5), (B,), generator=g)
+        num_pos[0] = 0
+        if B > 1:
+            num_pos[1] = P                                        # 3 * num_pos > P: everything
+        want = O.hard_negative_mask(v, num_pos)
+        got = D.ops.topk_mask(v.to(dev), (3 * num_pos).to(dev))
+        assert torch.equal(got.cpu(), want), (B, P)
+    # the SSD300 loss built on it equals the same loss with the double argsort
+    m = D.SSD300(20)
+    P = m.dboxes.shape[0]
+    gts = [O.synth_gt(i, 20, False) for i in (0, 5)]
+    gb, gl = [x[0] for x in gts], [x[1] for x in gts]
+    outs = (torch.randn(2, P, 4, generator=g).to(dev), (2 * torch.randn(2, P, 21, generator=g)).to(dev))
+    res = m.loss(outs, gb, gl)
+    tl, tlab, _ = O.assign_ssd(m.dboxes, gb, gl)[:3]
+    import torch.nn.functional as F
+    oc, ol = outs[1].cpu(), outs[0].cpu()
+    pos = tlab > 0
+    ln = F.cross_entropy(oc.view(-1, 21), tlab.view(-1), reduction='none').view(2, -1)
+    ln[pos] = 0
+    neg = O.hard_negative_mask(ln, pos.sum(dim=1))
+    N = pos.sum()
+    want_conf = F.cross_entropy(oc[pos + neg], tlab[pos + neg], reduction='sum') / N
+    assert abs(float(res['loss_conf']) - float(want_conf)) <= 1e-4 * abs(float(want_conf))
+
+
 # ----------------------------------------------------------------------------- full size
 
 def test_retinanet800_full_size(D, oracle, dev):

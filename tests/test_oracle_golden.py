@@ -118,3 +118,15 @@ def test_nms_c_matches_python_twin(oracle):
 def test_yolov3_pre_predict_is_unpinned():
     note = manifest()['notes']['yolov3_pre_predict']
     assert note.startswith('TypeError')   # the reference cannot run it: parity for this path is by formula only
+
+
+def test_hard_negative_mask_matches_reference(oracle):
+    """The fixture holds loss_neg / neg_mask as the reference's own SSD300.loss computed them."""
+    import numpy as np
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'hardneg_ssd300.npz'))
+    loss_neg = torch.from_numpy(d['loss_neg'])
+    want = torch.from_numpy(np.unpackbits(d['neg_mask'], axis=1)[:, :loss_neg.shape[1]]).bool()
+    got = oracle.hard_negative_mask(loss_neg, torch.from_numpy(d['num_pos']))
+    assert torch.equal(got, want)
+    assert got.sum(dim=1).tolist() == d['k'].tolist()
