@@ -38,8 +38,9 @@ constexpr int NB = 256;               // histogram bins per (image, class)
 constexpr int PASS_BLOCK = 512;       // fallback streaming passes
 constexpr int MAX_SEL_CLASSES = 128;  // LDS tables are sized for this many selected classes
 constexpr int MAX_TILE_ANCHORS = 16384;
-constexpr int SUB_ROWS = 64;          // anchors per LDS sub-tile (4 lanes per anchor row)
 constexpr int SCAN_BLOCK = 256;
+constexpr int LPR = 4;                // lanes that share one anchor row (8 was measured: no faster)
+constexpr int SUB_ROWS = SCAN_BLOCK / LPR;   // anchors per LDS sub-tile
 constexpr int SAMPLE_SUBS = 4;        // sampled sub-tiles per workgroup of select_sample
 constexpr int BITMAP_MAX_WORDS = 4096;  // finalize orders by anchor through a P-bit LDS bitmap up to this
 
@@ -86,13 +87,15 @@ __device__ inline unsigned long long make_key(float s, uint32_t key_thr, uint32_
 // Activation of one sub-tile: rows x C head outputs -> scores, four lanes per anchor row.
 // ---------------------------------------------------------------------------------------------
 
-__device__ inline float quad_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 1));
-    return fmaxf(v, __shfl_xor(v, 2));
+__device__ inline float quad_max(float v) {          // over the LPR lanes of a row
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
 }
 __device__ inline float quad_sum(float v) {
-    v += __shfl_xor(v, 1);
-    return v + __shfl_xor(v, 2);
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o);
+    return v;
 }
 __device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -145,13 +148,13 @@ __device__ inline void dma_issue(const SubGeom &g, float *s_buf, long long total
 
 // What a lane needs to recompute one score of its row from the LDS tile, bit for bit.
 struct RowCtx {
-    const float *row;   // &tile[row][sub]; element i sits at row[4*i]
+    const float *row;   // &tile[row][sub]; element i sits at row[LPR*i]
     float m, inv, sg;   // soft-max maximum, 1/sum, sigmoid of the extra input
 };
 
 template <int ACT>
 __device__ inline float rescore(const RowCtx &c, int i) {
-    const float v = c.row[4 * i];
+    const float v = c.row[LPR * i];
     if (ACT == ACT_SOFTMAX) return __expf(v - c.m) * c.inv;
     if (ACT == ACT_SOFTMAX_SIGMOID) return (__expf(v - c.m) * c.inv) * c.sg;
     if (ACT == ACT_SIGMOID_SIGMOID) return sigmoidf_(v) * c.sg;
@@ -163,16 +166,16 @@ __device__ inline float rescore(const RowCtx &c, int i) {
 template <int ACT, int EPT>
 __device__ inline bool subtile_scores(const float *s_tile, const float *__restrict__ extra, long long row_base,
                                       int rows, int C, int shift, float (&x)[EPT], RowCtx &ctx) {
-    const int r = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    const int r = threadIdx.x / LPR, sub = threadIdx.x % LPR;
     ctx.row = s_tile; ctx.m = 0.f; ctx.inv = 1.f; ctx.sg = 1.f;
     if (r >= rows) return false;
-    const float *row = s_tile + shift + r * C + sub;     // the tile has 4*EPT floats of slack behind it
+    const float *row = s_tile + shift + r * C + sub;     // the tile has LPR*EPT floats of slack behind it
     ctx.row = row;
     const float fill = (ACT == ACT_SOFTMAX || ACT == ACT_SOFTMAX_SIGMOID) ? -__builtin_inff() : 0.f;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
-        const float v = row[4 * i];
-        x[i] = (sub + 4 * i < C) ? v : fill;
+        const float v = row[LPR * i];
+        x[i] = (sub + LPR * i < C) ? v : fill;
     }
     if (ACT == ACT_SOFTMAX || ACT == ACT_SOFTMAX_SIGMOID) {
         float m = x[0];
@@ -255,14 +258,14 @@ __global__ __launch_bounds__(SCAN_BLOCK) void activate_scores_kernel(const float
     const long long sub1 = min((long long)sp.n_sub, sub0 + sp.subs_per_block);
     float *o = out + (size_t)b * sp.P * sp.C;
     const int C = sp.C;
-    const int r = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    const int r = threadIdx.x / LPR, sub = threadIdx.x % LPR;
     for_each_subtile<ACT, EPT>(in, extra, b, sp.P, C, sp.total_floats, sub0, sub1, 1, s_dynf, sp.tile_floats,
                                [&](float (&x)[EPT], bool valid, int r0, const RowCtx &) {
                                    if (!valid) return;
                                    float *orow = o + (size_t)(r0 + r) * C + sub;
 #pragma unroll
                                    for (int i = 0; i < EPT; ++i)
-                                       if (sub + 4 * i < C) orow[4 * i] = x[i];
+                                       if (sub + LPR * i < C) orow[LPR * i] = x[i];
                                },
                                [](long long) {});
 }
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_sample_kernel(const float *
     extern __shared__ float s_dynf[];
     const int b = blockIdx.y;
     const int cb = sp.cb, C = sp.C;
-    const int r = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    const int r = threadIdx.x / LPR, sub = threadIdx.x % LPR;
     const long long first = (long long)blockIdx.x * SAMPLE_SUBS * sp.sample_rate;
     const long long last = min((long long)sp.n_sub, first + (long long)SAMPLE_SUBS * sp.sample_rate);
     float *sb = samp + (size_t)b * sp.Cs * sp.ns_cap;
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_sample_kernel(const float *
                                    float *o = sb + (size_t)q * SUB_ROWS + r;
 #pragma unroll
                                    for (int i = 0; i < EPT; ++i) {
-                                       const int c = sub + 4 * i;
+                                       const int c = sub + LPR * i;
                                        if (c >= cb && c < C) o[(size_t)(c - cb) * ns_cap] = x[i];
                                    }
                                },
@@ -419,11 +422,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
     unsigned long long *wlist = blk_list + blk * sp.blk_cap + (size_t)wv * wcap;
     uint32_t wn = 0;
     // the lane's classes never change: their staging thresholds live in registers
-    const int r = tid >> 2, sub = tid & 3;
+    const int r = tid / LPR, sub = tid % LPR;
     float tlo[EPT];
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
-        const int c = sub + 4 * i;
+        const int c = sub + LPR * i;
         tlo[i] = (c >= cb && c < C && rb[c - cb].mode == RULE_STAGED) ? rb[c - cb].min_score : __builtin_inff();
     }
 
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
                     const int i = __ffsll((long long)pm) - 1;
                     pm &= pm - 1ull;
                     const float sc = rescore<ACT>(ctx, i);               // same arithmetic as x[i], bit for bit
-                    if (slot < wcap) wlist[slot] = pack_entry(okey(sc) - key_thr, (uint32_t)(sub + 4 * i - cb), p);
+                    if (slot < wcap) wlist[slot] = pack_entry(okey(sc) - key_thr, (uint32_t)(sub + LPR * i - cb), p);
                 }
                 wn += (uint32_t)__popcll(has);
                 has = __ballot(pm != 0ull);
@@ -948,11 +951,11 @@ struct SelPlan {
 // With a 1-in-rate sample, the score whose sample rank is m has, with probability about 1 - 3e-6
 // (z = 4.5 standard deviations of the binomial), at least top_k scores at or above it; `upper` bounds
 // the number of scores at or above it by the same margin on the other side.
-int ept_for(int64_t C) { return C <= 32 ? 8 : (C <= 96 ? 24 : (C <= 128 ? 32 : 64)); }
+int ept_for(int64_t C) { return (C <= 32 ? 32 : (C <= 96 ? 96 : (C <= 128 ? 128 : 256))) / LPR; }
 
 // LDS floats of one sub-tile: the data, the alignment shift, and 4*EPT floats of slack so that the
-// unconditional register loads of compute_subtile stay inside the buffer.
-int tile_floats_for(int64_t C) { return (int)(((SUB_ROWS * C + 4 * ept_for(C) + 8) / 4 + 1) * 4); }
+// unconditional register loads of the activation stay inside the buffer.
+int tile_floats_for(int64_t C) { return (int)(((SUB_ROWS * C + LPR * ept_for(C) + 8) / 4 + 1) * 4); }
 
 // Workgroups of the scan that are resident at once: LDS-limited, on every CU of the device.
 int64_t scan_resident_workgroups(int64_t C) {
@@ -1125,10 +1128,10 @@ template <template <int, int> class L, typename A>
 int dispatch_act_ept(int act, int ept, const A &a) {
 #define DETBOX_ROW(ACT)                                        \
     switch (ept) {                                             \
-        case 8: return L<ACT, 8>::run(a);                      \
-        case 24: return L<ACT, 24>::run(a);                    \
-        case 32: return L<ACT, 32>::run(a);                    \
-        default: return L<ACT, 64>::run(a);                    \
+        case 32 / LPR: return L<ACT, 32 / LPR>::run(a);        \
+        case 96 / LPR: return L<ACT, 96 / LPR>::run(a);        \
+        case 128 / LPR: return L<ACT, 128 / LPR>::run(a);      \
+        default: return L<ACT, 256 / LPR>::run(a);             \
     }
     switch (act) {
         case ACT_NONE: DETBOX_ROW(ACT_NONE)
