@@ -259,6 +259,14 @@ def main():
         roofline = dict(kernel=dom, bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
                         frac=achieved / HBM_PEAK_GBS, traffic=measured_traffic(args, dom), avg_us=dom_us,
                         launches=n, algorithmic_bytes=alg_bytes[dom])
+        # the streaming kernel of the path (reads the logits once), from the survey pass
+        streaming = None
+        if 'select_scan' in kern:
+            a = score_bytes / (kern['select_scan']['avg_us'] * 1e-6) / 1e9
+            streaming = dict(kernel='select_scan', bound='hbm', achieved=a, peak=HBM_PEAK_GBS, unit='GB/s',
+                             frac=a / HBM_PEAK_GBS, traffic=measured_traffic(args, 'select_scan'),
+                             avg_us=kern['select_scan']['avg_us'], algorithmic_bytes=score_bytes,
+                             note='survey pass: every kernel bracketed by events')
         anchor_bytes = {'fcos': 8, 'yolo': 20}.get(wl.w['family'], 16)
         bytes_img = ((52.0 if wl.w['family'] == 'fcos' else 48.0) * P + 24.0 * G_mean
                      + 4.0 * P * C + 16.0 * P + anchor_bytes * P + (4.0 * P if wl.ext is not None else 0.0) + 28.0 * n_cand
@@ -280,6 +288,7 @@ def main():
                        'images_per_gpu': B, 'global_batch': world * B, 'candidates_per_image': n_cand,
                        'kept_per_image': n_keep, 'gt_per_image': G_mean, 'parallelism': f'image-sharded x{world}'},
             'roofline': roofline,
+            'roofline_streaming': streaming,
             'cpu_baseline': cpu,
             'pipeline': {'algorithmic_bytes_per_image': bytes_img,
                          'hbm_frac_whole_step': bytes_img * ips / world / (HBM_PEAK_GBS * 1e9)},
