@@ -899,14 +899,23 @@ __global__ __launch_bounds__(256) void select_finalize_kernel(
         for (int w = 0; w < wave; ++w) base += s_wsum[w];
         for (int w = w0; w < w1; ++w) { s_wp[w] = base; base += (uint32_t)__popcll(s_bm[w]); }
         __syncthreads();
+        // ranks first, then the winners go through LDS in rank order so that the output rows leave coalesced
+        int rank[KPT];
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
+            rank[j] = -1;
             if (k[j] && k[j] >= cutoff) {
                 const uint32_t p = 0xffffffffu - (uint32_t)(k[j] & 0xffffffffull);
-                const uint32_t rank = s_wp[p >> 6] + (uint32_t)__popcll(s_bm[p >> 6] & ((1ull << (p & 63u)) - 1ull));
-                emit((int)rank, k[j]);
+                rank[j] = (int)(s_wp[p >> 6] + (uint32_t)__popcll(s_bm[p >> 6] & ((1ull << (p & 63u)) - 1ull)));
             }
         }
+        __syncthreads();                                                // bitmap and prefix are dead from here
+        unsigned long long *s_out = s_dyn64;                            // [take]
+#pragma unroll
+        for (int j = 0; j < KPT; ++j)
+            if (rank[j] >= 0 && rank[j] < take) s_out[rank[j]] = k[j];
+        __syncthreads();
+        for (int r = tid; r < take; r += 256) emit(r, s_out[r]);
     } else {
         // very large P: sort the staged keys, cut, then sort the survivors by anchor index
         unsigned long long *s_k = s_dyn64;                              // [cap]
@@ -1297,7 +1306,8 @@ extern "C" int detbox_select_decode(int decode_mode, int activation, const float
         dim3 grid((unsigned)Cs, (unsigned)B);
         const int words = (int)((P + 63) / 64);
         const int use_bitmap = words <= BITMAP_MAX_WORDS ? 1 : 0;
-        const size_t lds = use_bitmap ? (size_t)words * 12 + 16 : (size_t)cap * 8;
+        size_t lds = use_bitmap ? (size_t)words * 12 + 16 : (size_t)cap * 8;
+        if (use_bitmap && lds < (size_t)top_k * 8) lds = (size_t)top_k * 8;      // the winners in rank order reuse the bitmap
         const float4 *l4 = reinterpret_cast<const float4 *>(locs);
         float4 *ob = reinterpret_cast<float4 *>(out_boxes);
 #define DETBOX_FIN(D, K)                                                                                          \
