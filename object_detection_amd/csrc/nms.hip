@@ -374,7 +374,7 @@ __device__ inline QBox quantise_box(const float4 bx, const float area, const flo
     return q;
 }
 
-struct NmsFastLds { size_t keys, box, qbox, qt, kbox, removed, mask, misc, wprefix, total; };
+struct NmsFastLds { size_t keys, box, qbox, qt, kbox, kq, removed, mask, misc, wprefix, total; };
 
 __host__ __device__ inline NmsFastLds nms_fast_lds(int max_seg, int n2) {
     const size_t words_cap = (size_t)((max_seg + 63) >> 6);
@@ -386,6 +386,7 @@ __host__ __device__ inline NmsFastLds nms_fast_lds(int max_seg, int n2) {
     l.qbox = off;    off += (size_t)max_seg * 8;                       // quantised outer boxes (lo, hi)
     l.qt = off;      off += (((size_t)max_seg * 4 + 15) & ~(size_t)15); // threshold shares
     l.kbox = off;    off += 64 * 16;
+    l.kq = off;      off += 65 * 16;                                   // quantised kept boxes (+1: the sweep prefetches one ahead)
     l.removed = off; off += ((words_cap * 8 + 15) & ~(size_t)15);
     l.mask = off;    off += 64 * 8;
     l.misc = off;    off += 96;                                       // keep word; 4 x 4 floats of the extent reduction
@@ -417,6 +418,7 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
     uint2 *s_qbox = reinterpret_cast<uint2 *>(lds_base + ld.qbox);
     uint32_t *s_qt = reinterpret_cast<uint32_t *>(lds_base + ld.qt);
     float4 *s_kbox = reinterpret_cast<float4 *>(lds_base + ld.kbox);
+    uint4 *s_kq = reinterpret_cast<uint4 *>(lds_base + ld.kq);
     unsigned long long *s_removed = reinterpret_cast<unsigned long long *>(lds_base + ld.removed);
     unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(lds_base + ld.mask);
     unsigned long long *s_keepw = reinterpret_cast<unsigned long long *>(lds_base + ld.misc);
@@ -532,7 +534,12 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
                 rows &= rows - 1ull;
                 if ((keep >> i) & 1ull) keep &= ~readlane64(m, i);
             }
-            if ((keep >> lane) & 1ull) s_kbox[__popcll(keep & ((1ull << lane) - 1ull))] = s_box[c0 + lane];
+            if ((keep >> lane) & 1ull) {                     // compact the kept boxes: fp32 and quantised (share biased by 2^30)
+                const int rk = __popcll(keep & ((1ull << lane) - 1ull));
+                const uint2 q = s_qbox[c0 + lane];
+                s_kbox[rk] = s_box[c0 + lane];
+                s_kq[rk] = make_uint4(q.x, q.y, s_qt[c0 + lane] + Q_BIAS, 0u);
+            }
             if (lane == 0) { s_keepw[0] = keep; s_removed[ch] = valid & ~keep; }
         }
         __syncthreads();
@@ -553,8 +560,6 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
             if (any_act) {
                 const float4 kb = lane < nk ? s_kbox[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float ka = (kb.z - kb.x) * (kb.w - kb.y);
-                const QBox kq = quantise_box(kb, ka, lx, ly, scale, t_scale, q_ok);
-                const uint32_t kq_tb = kq.T + Q_BIAS;
                 unsigned long long hit[JPT];
 #pragma unroll
                 for (int m = 0; m < JPT; ++m) hit[m] = 0ull;
@@ -567,9 +572,10 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
                     if (act[m]) m_first = m;
                 auto sweep = [&](auto first_slot) {
                     constexpr int M0 = decltype(first_slot)::value;
+                    uint4 kq_next = s_kq[0];                     // broadcast LDS reads, one kept box ahead
                     for (int t = 0; t < nk; ++t) {
-                        const uint32_t klo = __builtin_amdgcn_readlane(kq.lo, t), khi = __builtin_amdgcn_readlane(kq.hi, t);
-                        const uint32_t ktb = __builtin_amdgcn_readlane(kq_tb, t);
+                        const uint32_t klo = kq_next.x, khi = kq_next.y, ktb = kq_next.z;
+                        kq_next = s_kq[t + 1];
                         // stage 1 for every live slot first (independent chains, one branch for all of them):
                         // integer upper bound of the intersection against the threshold shares
                         unsigned long long open_m[JPT];

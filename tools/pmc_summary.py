@@ -1,6 +1,6 @@
 import csv, collections, re, sys, glob
 for d in sys.argv[1:]:
-    f = glob.glob(d + '/*/*counter_collection.csv')[0]
+    f = (glob.glob(d + '/*/*counter_collection.csv') + glob.glob(d + '/*counter_collection.csv'))[0]
     rows = list(csv.DictReader(open(f)))
     agg = collections.defaultdict(lambda: collections.defaultdict(list)); meta = {}
     for r in rows:
