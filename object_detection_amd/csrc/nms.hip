@@ -85,30 +85,30 @@ __device__ inline void bitonic_desc_u64(unsigned long long *s, int n) {
 // thread tid.  Strides >= 256 are exchanges between registers of one thread, strides < 64 are wave
 // shuffles; only strides 64 and 128 go through LDS (`xch`, 256*R keys) and need barriers.  Keys at
 // e >= n2 must be zero: only the passes up to n2 run and they never move a key across an n2 boundary.
-template <int R, int KK>
+template <int R, int KK, int BLK>
 __device__ inline void bitonic_stage_u64(unsigned long long (&K)[R], unsigned long long *xch, const int tid) {
 #pragma unroll
     for (int j = KK >> 1; j > 0; j >>= 1) {
-        if (j >= 256) {
-            const int dm = j >> 8;
+        if (j >= BLK) {
+            const int dm = j / BLK;
 #pragma unroll
             for (int m = 0; m < R; ++m) {
                 const int pm = m ^ dm;
                 if (pm > m) {
                     const unsigned long long a = K[m], c = K[pm];
-                    const bool desc = ((m * 256) & KK) == 0;           // KK >= 512 here: the bit lies in m
+                    const bool desc = ((m * BLK) & KK) == 0;           // KK >= 2*BLK here: the bit lies in m
                     if (desc ? (a < c) : (a > c)) { K[m] = c; K[pm] = a; }
                 }
             }
         } else {
             if (j >= 64) {
 #pragma unroll
-                for (int m = 0; m < R; ++m) xch[m * 256 + tid] = K[m];
+                for (int m = 0; m < R; ++m) xch[m * BLK + tid] = K[m];
                 __syncthreads();
             }
 #pragma unroll
             for (int m = 0; m < R; ++m) {
-                const int e = m * 256 + tid;
+                const int e = m * BLK + tid;
                 const unsigned long long a = K[m];
                 const unsigned long long c = j >= 64 ? xch[e ^ j] : __shfl_xor(a, j);
                 const bool lower = (tid & j) == 0;
@@ -121,23 +121,24 @@ __device__ inline void bitonic_stage_u64(unsigned long long (&K)[R], unsigned lo
     }
 }
 
-template <int R, int KK>
+template <int R, int KK, int BLK>
 __device__ inline void bitonic_stages_u64(unsigned long long (&K)[R], unsigned long long *xch, const int n2, const int tid) {
-    if constexpr (KK <= 256 * R) {
+    if constexpr (KK <= BLK * R) {
         if (KK <= n2) {                                      // uniform over the workgroup
-            bitonic_stage_u64<R, KK>(K, xch, tid);
-            bitonic_stages_u64<R, KK * 2>(K, xch, n2, tid);
+            bitonic_stage_u64<R, KK, BLK>(K, xch, tid);
+            bitonic_stages_u64<R, KK * 2, BLK>(K, xch, n2, tid);
         }
     }
 }
 
-// Bitonic sort (descending) of 256*R keys held R per thread: element e = m*256 + tid lives in K[m] of
-// thread tid.  Strides >= 256 are exchanges between registers of one thread, strides < 64 are wave
-// shuffles; only strides 64 and 128 go through LDS (`xch`, 256*R keys) and need barriers.  Keys at
-// e >= n2 must be zero: only the stages up to n2 run and they never move a key across an n2 boundary.
-template <int R>
+// Bitonic sort (descending) of BLK*R keys held R per thread: element e = m*BLK + tid lives in K[m] of
+// thread tid.  Strides >= BLK are exchanges between registers of one thread, strides < 64 are wave
+// shuffles; only the strides in between (64 and 128 for BLK = 256, none for a single wave) go through
+// LDS (`xch`, BLK*R keys) and need barriers.  Keys at e >= n2 must be zero: only the stages up to n2 run
+// and they never move a key across an n2 boundary.
+template <int R, int BLK>
 __device__ inline void bitonic_desc_u64_regs(unsigned long long (&K)[R], unsigned long long *xch, const int n2, const int tid) {
-    bitonic_stages_u64<R, 2>(K, xch, n2, tid);
+    bitonic_stages_u64<R, 2, BLK>(K, xch, n2, tid);
 }
 
 __device__ inline unsigned long long uniform64(unsigned long long v) {
@@ -376,12 +377,12 @@ __device__ inline QBox quantise_box(const float4 bx, const float area, const flo
 
 struct NmsFastLds { size_t keys, box, qbox, qt, kbox, kq, removed, mask, misc, wprefix, total; };
 
-__host__ __device__ inline NmsFastLds nms_fast_lds(int max_seg, int n2) {
+__host__ __device__ inline NmsFastLds nms_fast_lds(int max_seg, int n2, int blk) {
     const size_t words_cap = (size_t)((max_seg + 63) >> 6);
     NmsFastLds l;
     size_t off = 0;
     l.keys = off;                                                     // sort exchange buffer, dead before the boxes arrive
-    const size_t xch = (size_t)(n2 > 256 ? n2 : 256) * 8;
+    const size_t xch = blk > 64 ? (size_t)(n2 > blk ? n2 : blk) * 8 : 0;           // a single wave sorts without LDS
     l.box = off;     off += (size_t)max_seg * 16 > xch ? (size_t)max_seg * 16 : xch;
     l.qbox = off;    off += (size_t)max_seg * 8;                       // quantised outer boxes (lo, hi)
     l.qt = off;      off += (((size_t)max_seg * 4 + 15) & ~(size_t)15); // threshold shares
@@ -396,8 +397,9 @@ __host__ __device__ inline NmsFastLds nms_fast_lds(int max_seg, int n2) {
 }
 
 // Five workgroups per CU (five waves per SIMD) keep a whole 80-class x 16-image launch resident in one round.
-template <int JPT>
-__global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <= 4 ? 5 : 1))) void nms_segments_fast_kernel(
+// BLK = 256: up to 4096 boxes per segment; BLK = 64: one wave per segment (up to 256 boxes), no barriers at all.
+template <int JPT, int BLK>
+__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == 256 && JPT <= 4 ? 5 : 1))) void nms_segments_fast_kernel(
     const float4 *__restrict__ boxes, const float *__restrict__ scores, const int32_t *__restrict__ seg_off,
     NmsParams np, float2 *__restrict__ kept, int32_t *__restrict__ kcount, int32_t *__restrict__ err) {
     extern __shared__ unsigned long long s_dyn[];
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
         if (threadIdx.x == 0) err[b] = 1;
         return;
     }
-    const NmsFastLds ld = nms_fast_lds(np.max_seg, np.n2);
+    const NmsFastLds ld = nms_fast_lds(np.max_seg, np.n2, BLK);
     char *lds_base = reinterpret_cast<char *>(s_dyn);
     unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(lds_base + ld.keys);
     float4 *s_box = reinterpret_cast<float4 *>(lds_base + ld.box);
@@ -441,13 +443,13 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
     unsigned long long K[JPT];
 #pragma unroll
     for (int m = 0; m < JPT; ++m) {
-        const int i = tid + m * NMS_BLOCK;
+        const int i = tid + m * BLK;
         K[m] = 0ull;
         if (i < n)   // every real key is above the zero padding: its low word is 0xffffffff - i > 0
             K[m] = ((unsigned long long)okey_from_bits(__float_as_uint(scores[row0 + i] + 0.0f)) << 32) |
                    (unsigned long long)(0xffffffffu - (uint32_t)i);
     }
-    bitonic_desc_u64_regs<JPT>(K, s_keys, n2, tid);
+    bitonic_desc_u64_regs<JPT, BLK>(K, s_keys, n2, tid);
     __syncthreads();                                     // the exchange buffer overlaps the box array
     // boxes in sorted order: LDS copy for the chunk phases, register copy of the thread's own boxes
     int orig[JPT];
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
     float lx = __builtin_inff(), ly = __builtin_inff(), hx = -__builtin_inff(), hy = -__builtin_inff();
 #pragma unroll
     for (int m = 0; m < JPT; ++m) {
-        const int j = tid + m * NMS_BLOCK;
+        const int j = tid + m * BLK;
         bj[m] = make_float4(0.f, 0.f, 0.f, 0.f);
         aj[m] = 0.f;
         orig[m] = 0;
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
             lx = fminf(lx, bj[m].x); ly = fminf(ly, bj[m].y); hx = fmaxf(hx, bj[m].z); hy = fmaxf(hy, bj[m].w);
         }
     }
-    for (int i = tid; i < words; i += NMS_BLOCK) s_removed[i] = 0ull;
+    for (int i = tid; i < words; i += BLK) s_removed[i] = 0ull;
     if (tid < 64) s_mask[tid] = 0ull;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -478,10 +480,12 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
     }
     if (lane == 0) { s_red[wv * 4 + 0] = lx; s_red[wv * 4 + 1] = ly; s_red[wv * 4 + 2] = hx; s_red[wv * 4 + 3] = hy; }
     __syncthreads();
-    lx = fminf(fminf(s_red[0], s_red[4]), fminf(s_red[8], s_red[12]));
-    ly = fminf(fminf(s_red[1], s_red[5]), fminf(s_red[9], s_red[13]));
-    hx = fmaxf(fmaxf(s_red[2], s_red[6]), fmaxf(s_red[10], s_red[14]));
-    hy = fmaxf(fmaxf(s_red[3], s_red[7]), fmaxf(s_red[11], s_red[15]));
+    lx = s_red[0]; ly = s_red[1]; hx = s_red[2]; hy = s_red[3];
+#pragma unroll
+    for (int w = 1; w < BLK / 64; ++w) {
+        lx = fminf(lx, s_red[4 * w]); ly = fminf(ly, s_red[4 * w + 1]);
+        hx = fmaxf(hx, s_red[4 * w + 2]); hy = fmaxf(hy, s_red[4 * w + 3]);
+    }
     // 16-bit grid over the extent of the segment; switched off (nothing is ever rejected early) when the
     // extent is not a sane positive number
     const float E = fmaxf(hx - lx, hy - ly);
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
     for (int m = 0; m < JPT; ++m) {
         const QBox q = quantise_box(bj[m], aj[m], lx, ly, scale, t_scale, q_ok);
         qlo[m] = q.lo; qhi[m] = q.hi; qTn[m] = Q_BIAS - q.T;
-        const int j = tid + m * NMS_BLOCK;
+        const int j = tid + m * BLK;
         if (j < n) { s_qbox[j] = make_uint2(q.lo, q.hi); s_qt[j] = q.T; }
     }
     __syncthreads();
@@ -505,9 +509,10 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
         const int cn = min(64, n - c0);
         const unsigned long long valid = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
         const unsigned long long alive0 = ~s_removed[ch] & valid;
-        {   // mutual suppression words of the chunk; rows rp and 63-rp together hold 63 pairs, 8 threads share them
-            const int rp = tid >> 3, s8 = tid & 7;
-            for (int c = s8; c < 63; c += 8) {
+        {   // mutual suppression words of the chunk; rows rp and 63-rp together hold 63 pairs, TPR threads share them
+            constexpr int TPR = BLK / 32;
+            const int rp = tid / TPR, s8 = tid % TPR;
+            for (int c = s8; c < 63; c += TPR) {
                 const bool first = c < 63 - rp;
                 const int i = first ? rp : 63 - rp;
                 const int j = first ? rp + 1 + c : c + 1;
@@ -553,7 +558,7 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
             bool any_act = false;
 #pragma unroll
             for (int m = 0; m < JPT; ++m) {
-                const int j = tid + m * NMS_BLOCK;
+                const int j = tid + m * BLK;
                 act[m] = __ballot(j >= c0 + 64 && j < n && !((rem_mask >> m) & 1u));
                 any_act |= act[m] != 0ull;
             }
@@ -625,7 +630,7 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
 #pragma unroll
                 for (int m = 0; m < JPT; ++m) {
                     if ((hit[m] >> lane) & 1ull) {
-                        const int j = tid + m * NMS_BLOCK;
+                        const int j = tid + m * BLK;
                         rem_mask |= 1u << m;
                         atomicOr(&s_removed[j >> 6], 1ull << (j & 63));
                     }
@@ -659,7 +664,7 @@ __global__ __launch_bounds__(NMS_BLOCK) __attribute__((amdgpu_waves_per_eu(JPT <
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < JPT; ++m) {
-        const int i = tid + m * NMS_BLOCK;
+        const int i = tid + m * BLK;
         if (i >= n) continue;
         const unsigned long long rem = s_removed[i >> 6];
         if ((rem >> (i & 63)) & 1ull) continue;
@@ -956,20 +961,27 @@ extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scor
         dim3 grid((unsigned)S, (unsigned)B);
         const float4 *b4 = reinterpret_cast<const float4 *>(boxes);
         if (fast) {
-            const size_t lds = nms_fast_lds(np.max_seg, np.n2).total;
-#define DETBOX_NMS_FAST(J)                                                                                       \
+            // one wave per segment pays off once there are enough segments to fill the chip with single waves;
+            // with few segments the four-wave kernel finishes each of them sooner
+            const int blk = (max_segment <= 256 && B * S >= 4096) ? 64 : 256;
+            const size_t lds = nms_fast_lds(np.max_seg, np.n2, blk).total;
+#define DETBOX_NMS_FAST(J, BLKC)                                                                                 \
     {                                                                                                            \
         if (lds > 64 * 1024)                                                                                     \
-            DETBOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_segments_fast_kernel<J>),          \
+            DETBOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_segments_fast_kernel<J, BLKC>),    \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
-        nms_segments_fast_kernel<J><<<grid, dim3(NMS_BLOCK), lds, st>>>(b4, scores, seg_offsets, np, kept_a, kcount, err); \
+        nms_segments_fast_kernel<J, BLKC><<<grid, dim3(BLKC), lds, st>>>(b4, scores, seg_offsets, np, kept_a, kcount, err); \
     }
-            const int jpt = (int)((max_segment + NMS_BLOCK - 1) / NMS_BLOCK);
-            if (jpt <= 1) DETBOX_NMS_FAST(1)
-            else if (jpt <= 2) DETBOX_NMS_FAST(2)
-            else if (jpt <= 4) DETBOX_NMS_FAST(4)
-            else if (jpt <= 8) DETBOX_NMS_FAST(8)
-            else DETBOX_NMS_FAST(16)
+            const int jpt = (int)((max_segment + blk - 1) / blk);
+            if (blk == 64) {
+                if (jpt <= 1) DETBOX_NMS_FAST(1, 64)
+                else if (jpt <= 2) DETBOX_NMS_FAST(2, 64)
+                else DETBOX_NMS_FAST(4, 64)
+            } else if (jpt <= 1) DETBOX_NMS_FAST(1, 256)
+            else if (jpt <= 2) DETBOX_NMS_FAST(2, 256)
+            else if (jpt <= 4) DETBOX_NMS_FAST(4, 256)
+            else if (jpt <= 8) DETBOX_NMS_FAST(8, 256)
+            else DETBOX_NMS_FAST(16, 256)
 #undef DETBOX_NMS_FAST
         } else {
             const size_t lds = nms_lds(np.max_seg, np.n2, np.presorted, np.in_lds).total;
