@@ -479,6 +479,22 @@ def test_nms_adversarial_geometry(D, oracle, dev):
         assert torch.equal(got.cpu(), want), ncls
 
 
+def test_nms_thousands_of_short_segments(D, oracle, dev):
+    """Launches with >= 4096 short segments take the one-wave-per-segment kernel: every register-slot
+    count of it (segments up to 64, 128 and 256 boxes) against the oracle."""
+    O = oracle
+    g = torch.Generator().manual_seed(91)
+    for ncls, per in ((4200, 9), (4100, 25), (4100, 48)):
+        n = ncls * per
+        boxes = rand_boxes(g, n, spread=0.3, size=0.25)
+        scores = (torch.rand(n, generator=g) * 64).round() / 64
+        idxs = torch.randint(0, ncls, (n,), generator=g)
+        idxs[: 4 * per] = 7                                        # one longer segment
+        want = O.batched_nms(boxes, scores, idxs, 0.45)
+        got = D.batched_nms(boxes.to(dev), scores.to(dev), idxs.to(dev), 0.45)
+        assert torch.equal(got.cpu(), want), (ncls, per)
+
+
 def test_predictor_run_generic_inputs(D, oracle, dev):
     """Ungrouped class ids take the per-image path; grouped ones the batched path; same dicts."""
     O = oracle
