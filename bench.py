@@ -25,7 +25,7 @@ sys.path.insert(0, REPO)
 
 import object_detection_amd as D  # noqa: E402
 from object_detection_amd import ops  # noqa: E402
-from object_detection_amd.dist import gather_detections  # noqa: E402
+from object_detection_amd.dist import RowExchange  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, spec
 
@@ -72,6 +72,7 @@ class Workload:
     def __init__(self, name, regime, rank, dev):
         w = WORKLOADS[name]
         self.name, self.regime, self.w, self.dev = name, regime, w, dev
+        self.exchange = None
         self.model = w['make']()
         m = self.model
         self.anchors_cpu = m._anchors_for_decode()
@@ -123,8 +124,13 @@ class Workload:
         keep, kc = ops.nms_candidates(c, 0.45)
         rows_ids, rows_vals, row_off = ops.pack_detections(c.boxes, c.scores, c.class_ids, keep, kc, self.ids, self.hw)
         if world > 1:
-            n = int(row_off[-1].item())
-            rows_ids, rows_vals = gather_detections(rows_ids[:n], rows_vals[:n])
+            # the exchange step: this rank's detections as a compact message; the all-gather of the previous
+            # batch's messages starts now, on a side stream, and overlaps this batch's kernels
+            if self.exchange is None:
+                self.exchange = RowExchange(keep_results=False)
+                self.hdr_rows = ops.wire_header_rows(self.B)
+            wire = ops.pack_wire(c.boxes, c.scores, c.class_ids, keep, kc, self.ids, self.hw, self.B)
+            self.exchange.submit(wire, self.B, self.hdr_rows)
         return targets, c, kc, rows_ids, rows_vals, row_off
 
 
@@ -167,6 +173,9 @@ def measured_traffic(args, kernel):
 
 
 def main():
+    if os.environ.get('DETBOX_BENCH_DEBUG'):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['DETBOX_BENCH_DEBUG']), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -182,18 +191,27 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus and rank == 0:
         print(f'[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE', file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # DETBOX_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    backend = os.environ.get('DETBOX_BENCH_BACKEND', 'nccl')
+    local_dev = local_rank % max(torch.cuda.device_count(), 1) if backend != 'nccl' else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device('cuda', local_dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     wl = Workload(args.workload, args.regime, rank, dev)
     B, P, C = wl.B, wl.P, wl.C
 
     def barrier():
         if world > 1:
+            if wl.exchange is not None:
+                wl.exchange.finish()            # every batch's all-gather is complete before the clock is read
+            torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 

@@ -176,6 +176,23 @@ int detbox_pack_detections(const float *boxes, const float *scores, const int64_
                            int64_t B, int64_t stride,
                            int64_t *rows_ids, double *rows_vals, int32_t *row_offsets, void *stream);
 
+/* ---- multi-GPU exchange of detections ---------------------------------------------------- */
+
+/* Compact, self-describing message with one rank's kept detections, for the all-gather that precedes
+ * evaluation (the reference is single-process: src/test.py:98-99 appends Predictor.run's rows; here every
+ * rank ships its images' rows).  No counterpart in the reference.
+ * wire: 32-bit words, 6 per row; detbox_wire_header_rows(images_cap) header rows, then up to B*stride
+ * detection rows (class id, x1, y1, x2, y2, score as fp32 bits), images in order, detections in keep
+ * order.  Header words: [0] rows, [1] B, [2..2+B] row offsets per image, then B image ids (low, high
+ * word), then B image sizes (H, W).  images_cap >= B must be the same on every rank (it fixes where the
+ * rows start).  The rows of detbox_pack_detections follow from these words bit for bit:
+ * x1*W, y1*H, (x2-x1)*W, (y2-y1)*H (fp32 differences, float64 products), score. */
+int64_t detbox_wire_header_rows(int64_t images_cap);
+int detbox_pack_wire(const float *boxes, const float *scores, const int64_t *class_ids,
+                     const int64_t *keep, const int32_t *keep_counts,
+                     const int64_t *image_ids, const int32_t *image_sizes,
+                     int64_t B, int64_t stride, int64_t images_cap, uint32_t *wire, void *stream);
+
 /* ---- per-kernel timing (HIP events on the launch stream) --------------------------------- */
 
 /* While enabled, every kernel launch is bracketed by hipEvents recorded on its stream.
@@ -184,7 +201,7 @@ int detbox_pack_detections(const float *boxes, const float *scores, const int64_
  * "box_iou", "assign_anchor", "assign_fixup", "assign_fcos", "activate_scores", "select_sample",
  * "select_plan", "select_scan", "select_bucket", "select_check", "select_materialize", "score_hist", "select_kth",
  * "select_refine", "select_emit", "select_finalize", "nms_segments", "nms_scan", "nms_merge",
- * "nms_write", "pack_detections", "topk_mask". */
+ * "nms_write", "pack_detections", "pack_wire", "topk_mask". */
 int detbox_profile_enable(int on);
 /* Restricts the timing to the one kernel called `name` (NULL or "" = every kernel again), so that a
  * timed run pays the event overhead for that kernel only. */

@@ -884,6 +884,59 @@ __global__ __launch_bounds__(256) void pack_detections_kernel(
     for (int i = threadIdx.x; i < 2 * nb; i += 256) rows_ids[2 * r0 + i] = s_ids[i];
 }
 
+// Wire form of the kept detections for the exchange between ranks: 32-bit words, six per row
+// (class id, x1, y1, x2, y2, score as fp32 bits), behind a header that makes the message self-describing:
+//   word 0: rows n, word 1: images B, then row_offsets[B+1], then the image ids (low, high word), then the
+//   image sizes (H, W); the rows start at word 6 * hdr_rows.
+// The float64 products of the result rows are a function of these words and the sizes, so a receiver
+// rebuilds exactly the rows pack_detections writes.
+__global__ __launch_bounds__(256) void pack_wire_kernel(
+    const float4 *__restrict__ boxes, const float *__restrict__ scores, const int64_t *__restrict__ cls,
+    const int64_t *__restrict__ keep, const int32_t *__restrict__ keep_counts,
+    const int64_t *__restrict__ image_ids, const int32_t *__restrict__ image_sizes, int B, long long stride,
+    int hdr_rows, uint32_t *__restrict__ wire) {
+    __shared__ int s_red[256];
+    __shared__ uint32_t s_rows[256 * 6];
+    const int b = blockIdx.y;
+    const int n = max(keep_counts[b], 0);
+    if (blockIdx.x != 0 && (int)(blockIdx.x * blockDim.x) >= n) return;
+    int acc = 0;
+    for (int i = threadIdx.x; i < b; i += blockDim.x) acc += max(keep_counts[i], 0);
+    s_red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const int row0 = s_red[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        wire[2 + b] = (uint32_t)row0;
+        const unsigned long long id = (unsigned long long)image_ids[b];
+        wire[2 + (B + 1) + 2 * b] = (uint32_t)id;
+        wire[2 + (B + 1) + 2 * b + 1] = (uint32_t)(id >> 32);
+        wire[2 + (B + 1) + 2 * B + 2 * b] = (uint32_t)image_sizes[2 * b];
+        wire[2 + (B + 1) + 2 * B + 2 * b + 1] = (uint32_t)image_sizes[2 * b + 1];
+        if (b == B - 1) { wire[0] = (uint32_t)(row0 + n); wire[1] = (uint32_t)B; wire[2 + B] = (uint32_t)(row0 + n); }
+    }
+    const int t0 = blockIdx.x * blockDim.x;
+    if (t0 >= n) return;
+    const int nb = min(256, n - t0);
+    const int t = t0 + threadIdx.x;
+    if (t < n) {
+        const size_t base = (size_t)b * stride;
+        const int64_t k = keep[base + t];
+        const float4 bx = boxes[base + k];
+        uint32_t *r = s_rows + 6 * threadIdx.x;
+        r[0] = (uint32_t)cls[base + k];
+        r[1] = __float_as_uint(bx.x); r[2] = __float_as_uint(bx.y);
+        r[3] = __float_as_uint(bx.z); r[4] = __float_as_uint(bx.w);
+        r[5] = __float_as_uint(scores[base + k]);
+    }
+    __syncthreads();
+    uint32_t *out = wire + 6 * ((size_t)hdr_rows + row0 + t0);
+    for (int i = threadIdx.x; i < 6 * nb; i += 256) out[i] = s_rows[i];
+}
+
 struct NmsLayout { size_t kept_a, kept_b, kcount, koff, err, total, zero_off, zero_bytes; };
 
 NmsLayout nms_layout(int64_t B, int64_t stride, int64_t S) {
@@ -1051,6 +1104,33 @@ extern "C" int detbox_pack_detections(const float *boxes, const float *scores, c
     pack_detections_kernel<<<dim3((unsigned)((stride + 255) / 256), (unsigned)B), dim3(256), 0, st>>>(
         reinterpret_cast<const float4 *>(boxes), scores, class_ids, keep, keep_counts, image_ids, image_sizes, (int)B,
         stride, rows_ids, rows_vals, row_offsets);
+    DETBOX_LAUNCH_CHECK();
+    return DETBOX_OK;
+}
+
+extern "C" int64_t detbox_wire_header_rows(int64_t images_cap) {
+    if (images_cap < 0) images_cap = 0;
+    return (2 + (images_cap + 1) + 4 * images_cap + 5) / 6;
+}
+
+extern "C" int detbox_pack_wire(const float *boxes, const float *scores, const int64_t *class_ids,
+                                const int64_t *keep, const int32_t *keep_counts,
+                                const int64_t *image_ids, const int32_t *image_sizes,
+                                int64_t B, int64_t stride, int64_t images_cap, uint32_t *wire, void *stream) {
+    DETBOX_CHECK_ARG(B >= 0 && stride >= 0 && images_cap >= B, "bad size");
+    DETBOX_CHECK_ARG(B <= 65535 && stride < (1ll << 31), "size too large");
+    DETBOX_CHECK_ARG(wire, "null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (B == 0 || stride == 0) {
+        DETBOX_HIP(hipMemsetAsync(wire, 0, (size_t)detbox_wire_header_rows(images_cap) * 6 * sizeof(uint32_t), st));
+        return DETBOX_OK;
+    }
+    DETBOX_CHECK_ARG(boxes && scores && class_ids && keep && keep_counts && image_ids && image_sizes, "null pointer");
+    DETBOX_CHECK_ARG((uintptr_t)boxes % 16 == 0, "boxes must be 16-byte aligned");
+    ProfScope ps("pack_wire", st);
+    pack_wire_kernel<<<dim3((unsigned)((stride + 255) / 256), (unsigned)B), dim3(256), 0, st>>>(
+        reinterpret_cast<const float4 *>(boxes), scores, class_ids, keep, keep_counts, image_ids, image_sizes, (int)B,
+        stride, (int)detbox_wire_header_rows(images_cap), wire);
     DETBOX_LAUNCH_CHECK();
     return DETBOX_OK;
 }

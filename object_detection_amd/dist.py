@@ -49,3 +49,134 @@ def gather_detections(rows_ids: torch.Tensor, rows_vals: torch.Tensor, group=Non
     ids = torch.cat([o[:c, :2].contiguous().view(torch.int64) for o, c in zip(out, counts)])
     vals = torch.cat([o[:c, 2:] for o, c in zip(out, counts)])
     return ids, vals
+
+
+# --------------------------------------------------------------------------------------------------
+# Pipelined exchange: compact messages, gathered on a side stream while the next batch is computed
+# --------------------------------------------------------------------------------------------------
+
+def unpack_wire(msg: torch.Tensor, header_rows: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One rank's message (int32 [header_rows + rows.., 6], see detbox_pack_wire) -> the result rows
+    (rows_ids [n,2] i64, rows_vals [n,5] f64) exactly as detbox_pack_detections writes them."""
+    words = msg.reshape(-1)
+    n, B = int(words[0]), int(words[1])
+    row_off = words[2:2 + B + 1].to(torch.int64)
+    idw = words[2 + B + 1:2 + B + 1 + 2 * B].to(torch.int64).reshape(B, 2)
+    ids = (idw[:, 0] & 0xffffffff) | (idw[:, 1] << 32)
+    sizes = words[2 + 3 * B + 1:2 + 5 * B + 1].reshape(B, 2)
+    rows = msg[header_rows:header_rows + n]
+    img = torch.searchsorted(row_off[1:].contiguous(), torch.arange(n, device=msg.device), right=True)
+    f = rows[:, 1:].contiguous().view(torch.float32)
+    W, H = sizes[img, 1].to(torch.float64), sizes[img, 0].to(torch.float64)
+    vals = torch.stack([f[:, 0].to(torch.float64) * W, f[:, 1].to(torch.float64) * H,
+                        (f[:, 2] - f[:, 0]).to(torch.float64) * W, (f[:, 3] - f[:, 1]).to(torch.float64) * H,
+                        f[:, 4].to(torch.float64)], dim=1)
+    rid = torch.stack([ids[img], rows[:, 0].to(torch.int64)], dim=1)
+    return rid, vals
+
+
+class RowExchange:
+    """All-gather of every batch's detections, one batch behind the computation.
+
+    submit(wire, images_cap) hands over this rank's message for the batch just launched (its row count is
+    still being computed on the device); the gather of the PREVIOUS batch is started at that moment, on a
+    side stream, so its transfer overlaps the kernels of the current batch and the host never waits for
+    the batch in flight.  finish() starts the last gather and waits for all of them.  Two collectives per
+    batch: the counts (to agree on the padded length) and the messages.  Works on gloo/CPU tensors too
+    (no streams there)."""
+
+    def __init__(self, group=None, keep_results: bool = True):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # RCCL moves device buffers; any other backend (gloo rehearsals) gets the message staged on the host
+        self.device_collectives = self.world > 1 and dist.get_backend(group) == 'nccl'
+        self.keep_results = keep_results
+        self.waiting = []        # submitted, gather not started: (wire, header_rows, event, pinned count)
+        self.flying = []         # gathers started: (work, out, header_rows, counts)
+        self.results = []        # per batch: (out [world, rows, 6], header_rows, counts)
+        self.comm = None
+        self.pins, self.pin_next = [], 0
+
+    def submit(self, wire: torch.Tensor, images_cap: int, header_rows: int):
+        ev = pin = None
+        if wire.is_cuda:
+            if self.comm is None:
+                self.comm = torch.cuda.Stream(wire.device)
+            if not self.pins:
+                self.pins = [torch.empty(1, dtype=torch.int32).pin_memory() for _ in range(4)]
+            pin = self.pins[self.pin_next % 4]       # at most two batches wait at any time
+            self.pin_next += 1
+            pin.copy_(wire.reshape(-1)[:1], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(wire.device))
+        item = (wire, header_rows, ev, pin)
+        if self.waiting:
+            self._start(self.waiting.pop(0))
+        self.waiting.append(item)
+
+    def _start(self, item):
+        wire, header_rows, ev, pin = item
+        if self.world == 1:
+            n = int(wire.reshape(-1)[0]) if ev is None else None
+            if ev is not None:
+                ev.synchronize()
+                n = int(pin[0])
+            self.flying.append((None, wire[:header_rows + n].unsqueeze(0), header_rows, [n]))
+            return
+        import contextlib
+        if ev is not None:
+            ev.synchronize()                       # the batch whose rows these are finished long ago
+            n = int(pin[0])
+        else:
+            n = int(wire.reshape(-1)[0])
+        if wire.is_cuda and self.device_collectives:
+            ctx = torch.cuda.stream(self.comm)
+            self.comm.wait_event(ev)
+        else:
+            ctx = contextlib.nullcontext()
+            if wire.is_cuda:
+                wire = wire[:header_rows + n].cpu()
+        with ctx:
+            mine = torch.tensor([n], dtype=torch.int64, device=wire.device)
+            counts = torch.empty(self.world, dtype=torch.int64, device=wire.device)
+            dist.all_gather_into_tensor(counts, mine, group=self.group)
+            counts = [int(c) for c in counts.tolist()]
+            rows = header_rows + max(max(counts), 0)
+            if wire.shape[0] >= rows:
+                send = wire[:rows]                 # rows beyond n are padding
+            else:                                  # another rank has more rows than this buffer holds
+                send = torch.zeros((rows, 6), dtype=torch.int32, device=wire.device)
+                send[:wire.shape[0]] = wire
+            out = torch.empty((self.world, rows, 6), dtype=torch.int32, device=wire.device)
+            work = dist.all_gather_into_tensor(out.view(self.world * rows, 6), send, group=self.group, async_op=True)
+            if wire.is_cuda:
+                wire.record_stream(self.comm)
+        self.flying.append((work, out, header_rows, counts))
+        while len(self.flying) > 2:                # retire old gathers (they finished long ago)
+            self._retire(self.flying.pop(0))
+
+    def _retire(self, f):
+        work, out, header_rows, counts = f
+        if work is not None:
+            work.wait()
+        if self.keep_results:
+            self.results.append((out, header_rows, counts))
+
+    def finish(self):
+        """Starts what is left, waits for every gather; returns the gathered messages per batch."""
+        while self.waiting:
+            self._start(self.waiting.pop(0))
+        for f in self.flying:
+            self._retire(f)
+        self.flying = []
+        if self.comm is not None:
+            torch.cuda.current_stream(self.comm.device).wait_stream(self.comm)
+        res, self.results = self.results, []
+        return res
+
+
+def unpack_gathered(batch) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(out [world, rows, 6], header_rows, counts) of one batch -> rows of all ranks in rank order."""
+    out, header_rows, counts = batch
+    parts = [unpack_wire(out[r], header_rows) for r in range(out.shape[0])]
+    return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])

@@ -260,6 +260,25 @@ def pack_detections(boxes, scores, class_ids, keep, keep_counts, image_ids: torc
     return rows_ids, rows_vals, row_off
 
 
+def wire_header_rows(images_cap: int) -> int:
+    return int(_lib.lib().detbox_wire_header_rows(int(images_cap)))
+
+
+def pack_wire(boxes, scores, class_ids, keep, keep_counts, image_ids: torch.Tensor, image_sizes: torch.Tensor,
+              images_cap: int) -> torch.Tensor:
+    """-> wire [header_rows + B*stride, 6] int32: the kept detections of this rank as a compact message
+    (see detbox_pack_wire); `dist.unpack_wire` turns gathered messages back into result rows."""
+    dev = boxes.device
+    B, stride = scores.shape
+    wire = torch.empty((wire_header_rows(images_cap) + B * stride, 6), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().detbox_pack_wire(_ptr(boxes), _ptr(scores), _ptr(class_ids), _ptr(keep),
+                                               keep_counts.data_ptr(), image_ids.data_ptr(), image_sizes.data_ptr(),
+                                               B, stride, int(images_cap), wire.data_ptr(), _stream(dev)),
+                   'detbox_pack_wire')
+    return wire
+
+
 # ------------------------------------------------------------------ per-kernel timing
 
 def topk_mask(values: torch.Tensor, k: torch.Tensor) -> torch.Tensor:

@@ -81,3 +81,47 @@ def box_close(a: torch.Tensor, b: torch.Tensor, rtol=1e-5):
     scale = b.abs().amax(dim=-1, keepdim=True).clamp(min=1e-30)
     ok = ((a - b).abs() <= rtol * scale) | (a == b) | (a.isnan() & b.isnan())
     return bool(ok.all())
+
+
+def wire_from_rows(per_image, image_ids, image_sizes, header_rows):
+    """Torch restatement of the wire message (include/detbox.h, detbox_pack_wire) for CPU tests:
+    per_image = list of (class_ids [n] i64, boxes [n,4] f32, scores [n] f32) in keep order."""
+    import torch
+    B = len(per_image)
+    counts = [int(p[0].numel()) for p in per_image]
+    n = sum(counts)
+    words = torch.zeros((header_rows + n) * 6, dtype=torch.int32)
+    off = [0]
+    for c in counts:
+        off.append(off[-1] + c)
+    words[0], words[1] = n, B
+    words[2:2 + B + 1] = torch.tensor(off, dtype=torch.int32)
+    for b in range(B):
+        iid = int(image_ids[b])
+        lo, hi = iid & 0xffffffff, (iid >> 32) & 0xffffffff
+        words[2 + B + 1 + 2 * b] = lo - (1 << 32) if lo >= (1 << 31) else lo
+        words[2 + B + 1 + 2 * b + 1] = hi - (1 << 32) if hi >= (1 << 31) else hi
+        words[2 + 3 * B + 1 + 2 * b] = int(image_sizes[b][0])
+        words[2 + 3 * B + 1 + 2 * b + 1] = int(image_sizes[b][1])
+    wire = words.reshape(-1, 6)
+    r = header_rows
+    for cls, boxes, scores in per_image:
+        k = cls.numel()
+        wire[r:r + k, 0] = cls.to(torch.int32)
+        wire[r:r + k, 1:5] = boxes.to(torch.float32).contiguous().view(torch.int32)
+        wire[r:r + k, 5] = scores.to(torch.float32).contiguous().view(torch.int32)
+        r += k
+    return wire
+
+
+def rows_from_detections(per_image, image_ids, image_sizes):
+    """The result rows (ids i64 [n,2], vals f64 [n,5]) as src/utilities/predictor.py:60-73 builds them."""
+    import torch
+    ids, vals = [], []
+    for b, (cls, boxes, scores) in enumerate(per_image):
+        H, W = float(image_sizes[b][0]), float(image_sizes[b][1])
+        bx = boxes.to(torch.float32)
+        ids.append(torch.stack([torch.full_like(cls, int(image_ids[b])), cls], dim=1))
+        vals.append(torch.stack([bx[:, 0].double() * W, bx[:, 1].double() * H, (bx[:, 2] - bx[:, 0]).double() * W,
+                                 (bx[:, 3] - bx[:, 1]).double() * H, scores.to(torch.float32).double()], dim=1))
+    return torch.cat(ids), torch.cat(vals)

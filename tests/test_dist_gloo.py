@@ -33,7 +33,7 @@ def _worker(rank, world, port, num_images, q):
     ids = torch.cat([r[0] for r in rows]) if rows else torch.zeros(0, 2, dtype=torch.int64)
     vals = torch.cat([r[1] for r in rows]) if rows else torch.zeros(0, 5, dtype=torch.float64)
     gids, gvals = gather_detections(ids, vals)
-    q.put((rank, gids, gvals))
+    q.put((rank, gids.numpy(), gvals.numpy()))      # arrays, not tensors: a tensor's shared-memory handle dies with this process
     dist.barrier()
     dist.destroy_process_group()
 
@@ -53,7 +53,7 @@ def _run(num_images, world=2):
     want_ids = torch.cat([r[0] for r in rows]) if rows else torch.zeros(0, 2, dtype=torch.int64)
     want_vals = torch.cat([r[1] for r in rows]) if rows else torch.zeros(0, 5, dtype=torch.float64)
     for _, gids, gvals in got:
-        assert torch.equal(gids, want_ids) and torch.equal(gvals, want_vals)
+        assert torch.equal(torch.from_numpy(gids), want_ids) and torch.equal(torch.from_numpy(gvals), want_vals)
 
 
 def test_shard_ranges_cover_batch():
@@ -70,3 +70,58 @@ def test_gather_two_ranks_even_and_ragged():
     _run(8)
     _run(5)       # uneven shards (3 + 2 images)
     _run(1)       # one rank has no image at all
+
+
+# ---- pipelined exchange of compact messages ------------------------------------------------------
+
+def _fake_dets(image_index: int):
+    g = torch.Generator().manual_seed(500 + image_index)
+    n = int(torch.randint(0, 9, (1,), generator=g))
+    return (torch.randint(1, 81, (n,), generator=g), torch.rand(n, 4, generator=g), torch.rand(n, generator=g))
+
+
+def _exchange_worker(rank, world, port, batches, per_rank, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import wire_from_rows
+    from object_detection_amd.dist import RowExchange, unpack_gathered
+    hdr = (2 + (per_rank + 1) + 4 * per_rank + 5) // 6
+    ex = RowExchange()
+    for k in range(batches):
+        imgs = [k * world * per_rank + rank * per_rank + i for i in range(per_rank - (1 if (rank == 1 and k == 1) else 0))]
+        dets = [_fake_dets(i) for i in imgs]
+        wire = wire_from_rows(dets, [(1 << 33) + i for i in imgs], [(100 + i, 200 + i) for i in imgs], hdr)
+        ex.submit(wire, per_rank, hdr)
+    got = [unpack_gathered(bt) for bt in ex.finish()]
+    q.put((rank, [(a.numpy(), b.numpy()) for a, b in got]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_exchange_pipelined_world2():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import rows_from_detections
+    world, batches, per_rank = 2, 3, 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, batches, per_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, per_batch in got:
+        assert len(per_batch) == batches
+        for k, (gids, gvals) in enumerate(per_batch):
+            imgs = []
+            for rank in range(world):
+                imgs += [k * world * per_rank + rank * per_rank + i
+                         for i in range(per_rank - (1 if (rank == 1 and k == 1) else 0))]
+            want_ids, want_vals = rows_from_detections([_fake_dets(i) for i in imgs], [(1 << 33) + i for i in imgs],
+                                                       [(100 + i, 200 + i) for i in imgs])
+            assert torch.equal(torch.from_numpy(gids), want_ids) and torch.equal(torch.from_numpy(gvals), want_vals)
