@@ -1,7 +1,7 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
 
 Bar: matched indices, labels, selected anchors/classes/scores and NMS keep-lists bit-exact;
-encoded / decoded coordinates within 1e-5 relative (fp32), as BASELINE.json's north_star states.
+encoded / decoded coordinates within 1e-5 relative (fp32).
 """
 import json
 
@@ -591,7 +591,7 @@ def test_wire_message_rebuilds_result_rows(D, oracle, dev):
 # ----------------------------------------------------------------------------- full size
 
 def test_retinanet800_full_size(D, oracle, dev):
-    """BASELINE config 2 shapes (P=120087, C=81, top_k=1000), one image against the oracle directly
+    """RetinaNet-800 benchmark shapes (P=120087, C=81, top_k=1000), one image against the oracle directly
     plus size-independent properties on a batch."""
     O = oracle
     m = D.RetinaNet(80, [100, 50, 25, 13, 7])
