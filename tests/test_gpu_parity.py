@@ -629,3 +629,47 @@ def test_retinanet800_full_size(D, oracle, dev):
     gb, gl = [g_[0] for g_ in gts], [g_[1] for g_ in gts]
     got = m.assign(gb, gl, dev, want_best=True)
     check_assign(got, O.assign_retinanet(m.pboxes, gb, gl), 'retina')
+
+
+def test_bench_workload_properties_full_batch(D, oracle, dev):
+    """The bench workload itself (RetinaNet-800, B=16, dense): size-independent properties of one whole
+    step, plus two of its images against the oracle NMS."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('bench', os.path.join(os.path.dirname(os.path.dirname(__file__)), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    wl = bench.Workload('retinanet800', 'dense', 0, dev)
+    targets, c, kc, rows_ids, rows_vals, row_off = wl.step(1)
+    B, stride = c.scores.shape
+    keep, kc2 = D.ops.nms_candidates(c, 0.45)
+    assert torch.equal(kc, kc2)
+    counts = c.counts.cpu()
+    seg = c.seg_offsets.cpu()
+    assert int(row_off[-1]) == int(kc.sum())
+    for b in range(B):
+        n, k = int(counts[b]), int(kc[b])
+        kp = keep[b, :k]
+        sc = c.scores[b][kp]
+        assert bool((sc[1:] <= sc[:-1]).all())                       # descending scores
+        assert int(kp.max()) < n and kp.unique().numel() == k        # valid, distinct rows
+        tie = sc[1:] == sc[:-1]
+        assert bool((kp[1:][tie] > kp[:-1][tie]).all())              # equal scores: ascending row index
+        assert torch.equal(seg[b, 1:] - seg[b, :-1], torch.bincount(c.class_ids[b, :n].cpu() - 1, minlength=80).to(torch.int32))
+    # idempotence: NMS over the kept boxes alone keeps every one of them
+    b = 3
+    k = int(kc[b])
+    kp = keep[b, :k]
+    again = D.batched_nms(c.boxes[b][kp], c.scores[b][kp], c.class_ids[b][kp], 0.45)
+    assert again.numel() == k and torch.equal(again, torch.arange(k, device=again.device))
+    for b in (0, 15):
+        n = int(counts[b])
+        want = oracle.batched_nms(c.boxes[b, :n].cpu(), c.scores[b, :n].cpu(), c.class_ids[b, :n].cpu(), 0.45)
+        assert torch.equal(keep[b, :int(kc[b])].cpu(), want)
+    # rows of the first image follow its keep list
+    k0 = int(kc[0])
+    assert torch.equal(rows_ids[:k0, 1], c.class_ids[0][keep[0, :k0]]) and bool((rows_ids[:k0, 0] == wl.ids[0]).all())
+    assert torch.equal(rows_vals[:k0, 4], c.scores[0][keep[0, :k0]].double())
+    # assignment: every ground-truth box got its best anchor labelled positive or ignored, never background
+    locs, labels, matched = targets[:3]
+    assert labels.shape == (B, wl.P) and int((labels > 0).sum()) > 0
