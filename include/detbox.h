@@ -105,6 +105,21 @@ int detbox_assign_fcos(const float *points, const float *regress_ranges, int64_t
  * bytes (0 / 1).  k[b] <= 0 selects nothing, k[b] >= P everything. */
 int detbox_topk_mask(const float *values, const int64_t *k, int64_t B, int64_t P, uint8_t *out_mask, void *stream);
 
+/* Focal confidence loss, summed over the rows that take part (label >= 0; the ignore label -1 and any
+ * label >= C are skipped).  Replaces the boolean-mask gather and focal_loss(..., reduction='sum') of
+ * src/models/losses.py:5-9 as called at src/models/retinanet.py:215 and src/models/fcos.py:271:
+ *   loss_row = -((alpha * (1 - pt)^gamma) * log_pt),  pt = softmax(logits[row])[label],
+ *   log_pt = log_softmax(logits[row])[label].
+ * logits [rows, C] (C <= 256), labels [rows]; *loss_sum (device, float64) receives the sum.
+ * The backward call writes grad_logits [rows, C] = *grad_scale * d(sum)/d(logits) (zero rows where the
+ * label does not take part); grad_scale is a device scalar (the upstream gradient, e.g. 1/N).
+ * Floating point: the sum is accumulated in float64, so it differs from the reference's fp32 sum only by
+ * the reference's own rounding (tested to 1e-5 relative). */
+int detbox_focal_loss_forward(const float *logits, const int64_t *labels, int64_t rows, int64_t C,
+                              float alpha, float gamma, double *loss_sum, void *stream);
+int detbox_focal_loss_backward(const float *logits, const int64_t *labels, int64_t rows, int64_t C,
+                               float alpha, float gamma, const float *grad_scale, float *grad_logits, void *stream);
+
 /* ---- inference: activation + threshold + exact top-k + decode ---------------------------- */
 
 /* activations applied to the head output before the threshold */
@@ -201,7 +216,7 @@ int detbox_pack_wire(const float *boxes, const float *scores, const int64_t *cla
  * "box_iou", "assign_anchor", "assign_fixup", "assign_fcos", "activate_scores", "select_sample",
  * "select_plan", "select_scan", "select_bucket", "select_check", "select_materialize", "score_hist", "select_kth",
  * "select_refine", "select_emit", "select_finalize", "nms_segments", "nms_scan", "nms_merge",
- * "nms_write", "pack_detections", "pack_wire", "topk_mask". */
+ * "nms_write", "pack_detections", "pack_wire", "topk_mask", "focal_forward", "focal_backward". */
 int detbox_profile_enable(int on);
 /* Restricts the timing to the one kernel called `name` (NULL or "" = every kernel again), so that a
  * timed run pays the event overhead for that kernel only. */

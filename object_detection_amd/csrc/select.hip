@@ -150,6 +150,7 @@ __device__ inline void dma_issue(const SubGeom &g, float *s_buf, long long total
 struct RowCtx {
     const float *row;   // &tile[row][sub]; element i sits at row[LPR*i]
     float m, inv, sg;   // soft-max maximum, 1/sum, sigmoid of the extra input
+    float sum;          // soft-max denominator
 };
 
 template <int ACT>
@@ -167,7 +168,7 @@ template <int ACT, int EPT>
 __device__ inline bool subtile_scores(const float *s_tile, const float *__restrict__ extra, long long row_base,
                                       int rows, int C, int shift, float (&x)[EPT], RowCtx &ctx) {
     const int r = threadIdx.x / LPR, sub = threadIdx.x % LPR;
-    ctx.row = s_tile; ctx.m = 0.f; ctx.inv = 1.f; ctx.sg = 1.f;
+    ctx.row = s_tile; ctx.m = 0.f; ctx.inv = 1.f; ctx.sg = 1.f; ctx.sum = 1.f;
     if (r >= rows) return false;
     const float *row = s_tile + shift + r * C + sub;     // the tile has LPR*EPT floats of slack behind it
     ctx.row = row;
@@ -190,7 +191,7 @@ __device__ inline bool subtile_scores(const float *s_tile, const float *__restri
         }
         sum = quad_sum(sum);
         const float inv = 1.0f / sum;
-        ctx.m = m; ctx.inv = inv;
+        ctx.m = m; ctx.inv = inv; ctx.sum = sum;
         if (ACT == ACT_SOFTMAX_SIGMOID) {
             const float sg = sigmoidf_(extra[row_base + r]);
             ctx.sg = sg;
@@ -268,6 +269,95 @@ __global__ __launch_bounds__(SCAN_BLOCK) void activate_scores_kernel(const float
                                        if (sub + LPR * i < C) orow[LPR * i] = x[i];
                                },
                                [](long long) {});
+}
+
+// ---------------------------------------------------------------------------------------------
+// Focal loss over the anchors that take part in the confidence loss (label >= 0), summed; replaces the
+// boolean-mask gather + softmax + log_softmax + nll_loss of src/models/losses.py:5-9 as called at
+// src/models/retinanet.py:215 and src/models/fcos.py:271:
+//     loss_row = -((alpha * (1 - pt)^gamma) * log_pt),  pt = softmax(x)[t],  log_pt = (x_t - max) - log(sum)
+// The rows stream through the same LDS sub-tiles as the selection; the [rows, C] gather never exists.
+// The sum is accumulated in double.  Backward: d loss_row / d x_j = dL/dlog_pt * ((j == t) - p_j) with
+// dL/dlog_pt = -alpha * ((1 - pt)^gamma - gamma * log_pt * pt * (1 - pt)^(gamma - 1)); rows that do not
+// take part get zero gradients.
+// ---------------------------------------------------------------------------------------------
+
+__device__ inline float pow_gamma(float base, float gamma) {
+    if (gamma == 2.0f) return base * base;                 // what torch's pow does for an exponent of 2
+    if (gamma == 1.0f) return base;
+    if (gamma == 0.0f) return 1.0f;
+    return powf(base, gamma);
+}
+
+template <int EPT>
+__global__ __launch_bounds__(SCAN_BLOCK) void focal_forward_kernel(const float *__restrict__ in,
+                                                                   const int64_t *__restrict__ labels, int rows, int C,
+                                                                   int subs_per_block, int n_sub, int tile_floats,
+                                                                   float alpha, float gamma, double *__restrict__ loss_sum) {
+    extern __shared__ float s_dynf[];
+    __shared__ double s_part[SCAN_BLOCK / 64];
+    const int tid = threadIdx.x;
+    const int r = tid / LPR, sub = tid % LPR;
+    const long long sub0 = (long long)blockIdx.x * subs_per_block;
+    const long long sub1 = min((long long)n_sub, sub0 + subs_per_block);
+    double acc = 0.0;
+    for_each_subtile<ACT_SOFTMAX, EPT>(in, nullptr, 0, rows, C, (long long)rows * C, sub0, sub1, 1, s_dynf, tile_floats,
+                                       [&](float (&x)[EPT], bool valid, int r0, const RowCtx &ctx) {
+                                           if (!valid) return;
+                                           const long long t = labels[r0 + r];
+                                           if (t < 0 || t >= C || (int)(t % LPR) != sub) return;   // one lane per row
+                                           const float d = ctx.row[LPR * (int)(t / LPR)] - ctx.m;
+                                           const float pt = __expf(d) * ctx.inv;
+                                           const float log_pt = d - logf(ctx.sum);
+                                           acc += (double)(-((alpha * pow_gamma(1.0f - pt, gamma)) * log_pt));
+                                       },
+                                       [](long long) {});
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((tid & 63) == 0) s_part[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < SCAN_BLOCK / 64; ++w) t += s_part[w];
+        if (t != 0.0) atomicAdd(loss_sum, t);
+    }
+}
+
+template <int EPT>
+__global__ __launch_bounds__(SCAN_BLOCK) void focal_backward_kernel(const float *__restrict__ in,
+                                                                    const int64_t *__restrict__ labels, int rows, int C,
+                                                                    int subs_per_block, int n_sub, int tile_floats,
+                                                                    float alpha, float gamma,
+                                                                    const float *__restrict__ grad_scale,
+                                                                    float *__restrict__ grad) {
+    extern __shared__ float s_dynf[];
+    const int tid = threadIdx.x;
+    const int r = tid / LPR, sub = tid % LPR;
+    const long long sub0 = (long long)blockIdx.x * subs_per_block;
+    const long long sub1 = min((long long)n_sub, sub0 + subs_per_block);
+    const float gs = *grad_scale;
+    for_each_subtile<ACT_SOFTMAX, EPT>(in, nullptr, 0, rows, C, (long long)rows * C, sub0, sub1, 1, s_dynf, tile_floats,
+                                       [&](float (&x)[EPT], bool valid, int r0, const RowCtx &ctx) {
+                                           if (!valid) return;
+                                           const long long t = labels[r0 + r];
+                                           float *orow = grad + (size_t)(r0 + r) * C + sub;
+                                           const bool takes_part = t >= 0 && t < C;
+                                           float g = 0.0f;                       // gs * dL/dlog_pt, the same in the row's lanes
+                                           if (takes_part) {
+                                               const float d = ctx.row[LPR * (int)(t / LPR) - sub + (int)(t % LPR)] - ctx.m;
+                                               const float pt = __expf(d) * ctx.inv;
+                                               const float log_pt = d - logf(ctx.sum);
+                                               const float om = 1.0f - pt;
+                                               const float dw = gamma == 0.0f ? 0.0f : gamma * pow_gamma(om, gamma - 1.0f);
+                                               g = gs * (-alpha * (pow_gamma(om, gamma) - (log_pt * pt) * dw));
+                                           }
+#pragma unroll
+                                           for (int i = 0; i < EPT; ++i) {
+                                               const int c = sub + LPR * i;
+                                               if (c < C) orow[LPR * i] = takes_part ? g * ((c == t ? 1.0f : 0.0f) - x[i]) : 0.0f;
+                                           }
+                                       },
+                                       [](long long) {});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1332,4 +1422,79 @@ extern "C" int detbox_select_decode(int decode_mode, int activation, const float
         DETBOX_LAUNCH_CHECK();
     }
     return DETBOX_OK;
+}
+
+namespace {
+
+struct FocalArgs {
+    const float *in;
+    const int64_t *labels;
+    int64_t rows, C;
+    float alpha, gamma;
+    double *loss_sum;
+    const float *grad_scale;
+    float *grad;
+    hipStream_t s;
+};
+
+template <int ACT, int EPT>
+struct LaunchFocal {
+    static int run(const FocalArgs &a) {
+        const int n_sub = (int)((a.rows + SUB_ROWS - 1) / SUB_ROWS);
+        const int64_t resident = scan_resident_workgroups(a.C);
+        int spb = (int)((n_sub + resident - 1) / resident);
+        if (spb < 1) spb = 1;
+        const unsigned gx = (unsigned)((n_sub + spb - 1) / spb);
+        const int tile_floats = tile_floats_for(a.C);
+        const size_t lds = 2 * (size_t)tile_floats * 4;
+        if (a.grad == nullptr) {
+            if (int rc = set_lds(focal_forward_kernel<EPT>, lds)) return rc;
+            DETBOX_HIP(hipMemsetAsync(a.loss_sum, 0, sizeof(double), a.s));
+            ProfScope ps("focal_forward", a.s);
+            focal_forward_kernel<EPT><<<dim3(gx), dim3(SCAN_BLOCK), lds, a.s>>>(a.in, a.labels, (int)a.rows, (int)a.C, spb, n_sub,
+                                                                               tile_floats, a.alpha, a.gamma, a.loss_sum);
+            DETBOX_LAUNCH_CHECK();
+        } else {
+            if (int rc = set_lds(focal_backward_kernel<EPT>, lds)) return rc;
+            ProfScope ps("focal_backward", a.s);
+            focal_backward_kernel<EPT><<<dim3(gx), dim3(SCAN_BLOCK), lds, a.s>>>(a.in, a.labels, (int)a.rows, (int)a.C, spb, n_sub,
+                                                                                tile_floats, a.alpha, a.gamma, a.grad_scale, a.grad);
+            DETBOX_LAUNCH_CHECK();
+        }
+        return DETBOX_OK;
+    }
+};
+
+int focal_check(const float *logits, const int64_t *labels, int64_t rows, int64_t C) {
+    DETBOX_CHECK_ARG(rows >= 0 && C >= 1, "bad size");
+    DETBOX_CHECK_ARG(C <= 256, "more than 256 classes are not supported");
+    DETBOX_CHECK_ARG(rows < (1ll << 31) - SUB_ROWS && rows * C < (1ll << 40), "size too large");
+    DETBOX_CHECK_ARG(rows == 0 || (logits && labels), "null pointer");
+    DETBOX_CHECK_ARG((uintptr_t)logits % 16 == 0, "logits must be 16-byte aligned");
+    return DETBOX_OK;
+}
+
+}  // namespace
+
+extern "C" int detbox_focal_loss_forward(const float *logits, const int64_t *labels, int64_t rows, int64_t C,
+                                         float alpha, float gamma, double *loss_sum, void *stream) {
+    if (int rc = focal_check(logits, labels, rows, C)) return rc;
+    DETBOX_CHECK_ARG(loss_sum, "null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (rows == 0) {
+        DETBOX_HIP(hipMemsetAsync(loss_sum, 0, sizeof(double), s));
+        return DETBOX_OK;
+    }
+    FocalArgs a{logits, labels, rows, C, alpha, gamma, loss_sum, nullptr, nullptr, s};
+    return dispatch_act_ept<LaunchFocal>(ACT_SOFTMAX, ept_for(C), a);
+}
+
+extern "C" int detbox_focal_loss_backward(const float *logits, const int64_t *labels, int64_t rows, int64_t C,
+                                          float alpha, float gamma, const float *grad_scale, float *grad_logits,
+                                          void *stream) {
+    if (int rc = focal_check(logits, labels, rows, C)) return rc;
+    DETBOX_CHECK_ARG(rows == 0 || (grad_scale && grad_logits), "null pointer");
+    if (rows == 0) return DETBOX_OK;
+    FocalArgs a{logits, labels, rows, C, alpha, gamma, nullptr, grad_scale, grad_logits, static_cast<hipStream_t>(stream)};
+    return dispatch_act_ept<LaunchFocal>(ACT_SOFTMAX, ept_for(C), a);
 }

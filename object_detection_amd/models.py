@@ -175,8 +175,8 @@ class RetinaNet(_BoxOps):
         neg_mask = target_labels == 0
         N = pos_mask.sum()
         loss_loc = F.smooth_l1_loss(out_locs[pos_mask], target_locs[pos_mask], reduction='sum') / N
-        sel = pos_mask + neg_mask
-        loss_conf = focal_loss(out_confs[sel], target_labels[sel], reduction='sum') / N
+        # Step 4 fused: rows with label -1 (ignored) are skipped inside the kernel (retinanet.py:215)
+        loss_conf = ops.focal_loss_sum(out_confs, target_labels) / N
         return {'loss': loss_conf + loss_loc, 'loss_loc': loss_loc, 'loss_conf': loss_conf}
 
 
@@ -213,8 +213,7 @@ class FCOS(_BoxOps):
         N = pos_mask.sum()
         loss_loc = iou_loss_with_distance(out_locs[pos_mask].exp(), target_locs[pos_mask], reduction='sum') / target_cents[pos_mask].sum()
         loss_cent = F.binary_cross_entropy_with_logits(out_cents[pos_mask], target_cents[pos_mask], reduction='sum') / N
-        sel = pos_mask + neg_mask
-        loss_conf = focal_loss(out_confs[sel], target_labels[sel], reduction='sum') / N
+        loss_conf = ops.focal_loss_sum(out_confs, target_labels) / N         # fcos.py:271, fused
         return {'loss': loss_conf + loss_cent + loss_loc, 'loss_loc': loss_loc, 'loss_cent': loss_cent, 'loss_conf': loss_conf}
 
 

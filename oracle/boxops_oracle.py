@@ -599,3 +599,16 @@ def hard_negative_mask(loss_neg: torch.Tensor, num_pos: torch.Tensor) -> torch.T
     here (and in the build) the lower index wins."""
     rank = loss_neg.argsort(dim=1, descending=True, stable=True).argsort(dim=1)
     return rank < (3 * num_pos).reshape(-1, 1)
+
+
+def focal_loss_sum(logits: torch.Tensor, labels: torch.Tensor, alpha: float = 0.25, gamma: float = 2) -> torch.Tensor:
+    """src/models/losses.py:5-9 with reduction='sum' over the rows the callers select
+    (`out_confs[pos_mask + neg_mask]`, src/models/retinanet.py:215, src/models/fcos.py:271): labels >= 0."""
+    import torch.nn.functional as F
+    C = logits.shape[-1]
+    x, t = logits.reshape(-1, C), labels.reshape(-1)
+    sel = t >= 0
+    x, t = x[sel], t[sel]
+    pt = F.softmax(x, dim=-1)
+    log_pt = F.log_softmax(x, dim=-1)
+    return F.nll_loss(alpha * (1 - pt).pow(gamma) * log_pt, t, reduction='sum')

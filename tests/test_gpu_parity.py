@@ -588,6 +588,41 @@ def test_wire_message_rebuilds_result_rows(D, oracle, dev):
             assert torch.equal(gid, rid[:n]) and torch.equal(gv, rv[:n])
 
 
+def test_focal_loss_fused_forward_backward(D, oracle, dev):
+    """Fused focal loss against the reference's own loss_conf (golden) and, value and gradient, against the
+    oracle's restatement of src/models/losses.py:5-9.  Floating point: 1e-5 relative on the sum (the kernel
+    accumulates in float64, the reference in fp32), 1e-5 of the largest gradient entry on the gradient."""
+    import numpy as np
+    import os
+    O = oracle
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'focal_retinanet_small.npz'))
+    x, t = torch.from_numpy(d['out_confs']), torch.from_numpy(d['target_labels'])
+    got = D.ops.focal_loss_sum(x.to(dev), t.to(dev)) / int(d['num_pos'])
+    assert abs(float(got) - float(d['loss_conf'])) <= 1e-5 * abs(float(d['loss_conf']))
+    g = torch.Generator().manual_seed(8)
+    for rows, C, alpha, gamma in ((1, 2, 0.25, 2.0), (63, 21, 0.25, 2.0), (1000, 81, 0.25, 2.0), (4097, 5, 0.5, 1.5),
+                                  (300, 130, 1.0, 0.0), (5000, 200, 0.25, 3.0)):
+        xs = (2.0 * torch.randn(rows, C, generator=g)).requires_grad_(True)
+        ts = torch.randint(-1, C, (rows,), generator=g)
+        want = O.focal_loss_sum(xs, ts, alpha, gamma)
+        (want / 7.0).backward()
+        xg = xs.detach().to(dev).requires_grad_(True)
+        got = D.ops.focal_loss_sum(xg, ts.to(dev), alpha, gamma)
+        (got / 7.0).backward()
+        assert abs(float(got.detach()) - float(want.detach())) <= 1e-5 * max(abs(float(want.detach())), 1e-6), (rows, C)
+        scale = float(xs.grad.abs().max())
+        assert float((xg.grad.cpu() - xs.grad).abs().max()) <= 1e-5 * max(scale, 1e-12), (rows, C, gamma)
+        assert bool((xg.grad.cpu()[ts < 0] == 0).all())
+    # the RetinaNet loss built on it
+    m = D.RetinaNet(20, [8, 4, 2, 1, 1])
+    P = m.pboxes.shape[0]
+    gts = [O.synth_gt(i, 20, False) for i in (2, 9)]
+    gb, gl = [q[0] for q in gts], [q[1] for q in gts]
+    outs = (torch.randn(2, P, 4, generator=g).to(dev), x.to(dev))
+    res = m.loss(outs, gb, gl)
+    assert abs(float(res['loss_conf']) - float(d['loss_conf'])) <= 1e-5 * abs(float(d['loss_conf']))
+
+
 # ----------------------------------------------------------------------------- full size
 
 def test_retinanet800_full_size(D, oracle, dev):

@@ -130,3 +130,12 @@ def test_hard_negative_mask_matches_reference(oracle):
     got = oracle.hard_negative_mask(loss_neg, torch.from_numpy(d['num_pos']))
     assert torch.equal(got, want)
     assert got.sum(dim=1).tolist() == d['k'].tolist()
+
+
+def test_focal_loss_matches_reference(oracle):
+    """loss_conf as the reference's own RetinaNet.loss computed it (fp32, same operations: exact)."""
+    import numpy as np
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'focal_retinanet_small.npz'))
+    got = oracle.focal_loss_sum(torch.from_numpy(d['out_confs']), torch.from_numpy(d['target_labels'])) / int(d['num_pos'])
+    assert abs(float(got) - float(d['loss_conf'])) <= 1e-6 * abs(float(d['loss_conf']))
