@@ -130,8 +130,10 @@ class SSD300(_BoxOps):
         neg_mask = ops.topk_mask(loss_neg, 3 * pos_mask.sum(dim=1))      # hard-negative mining, ssd300.py:277-278
         N = pos_mask.sum()
         loss_loc = F.smooth_l1_loss(out_locs[pos_mask], target_locs[pos_mask], reduction='sum') / N
-        sel = pos_mask + neg_mask
-        loss_conf = F.cross_entropy(out_confs[sel], target_labels[sel], reduction='sum') / N
+        # Step 4 (ssd300.py:288): cross entropy over positives and mined negatives = the fused focal sum with
+        # alpha = 1, gamma = 0; every other row carries the ignore label
+        sel_labels = torch.where(pos_mask | neg_mask, target_labels, torch.full_like(target_labels, -1))
+        loss_conf = ops.focal_loss_sum(out_confs, sel_labels, 1.0, 0.0) / N
         return {'loss': loss_conf + alpha * loss_loc, 'loss_loc': loss_loc, 'loss_conf': loss_conf}
 
 
