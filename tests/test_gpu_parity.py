@@ -623,6 +623,37 @@ def test_focal_loss_fused_forward_backward(D, oracle, dev):
     assert abs(float(res['loss_conf']) - float(d['loss_conf'])) <= 1e-5 * abs(float(d['loss_conf']))
 
 
+def test_models_loss_level2_matches_reference(D, oracle, dev):
+    """loss() of every family on the GPU against the scalars the reference's own loss() returned for the
+    same seeded inputs (tests/golden/loss_values.json).  Step 1 is bit-exact; the sums that follow run
+    in a different order on the GPU: 1e-4 relative."""
+    import json
+    import os
+    O = oracle
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'loss_values.json')) as f:
+        cases = json.load(f)['cases']
+    fk = [8, 4, 2, 1, 1]
+    models = {'ssd300': D.SSD300(20), 'retinanet_small': D.RetinaNet(20, fk), 'fcos_small': D.FCOS(20, fk),
+              'yolov3': D.YoloV3(20)}
+    for name, case in cases.items():
+        m = models[name]
+        g = torch.Generator().manual_seed(case['seed'])
+        P, C = case['P'], case['C']
+        locs = torch.randn(2, P, 4, generator=g)
+        confs = 1.5 * torch.randn(2, P, C, generator=g)
+        if case['family'] == 'fcos':
+            outs = (locs, confs, torch.randn(2, P, generator=g))
+        elif case['family'] == 'yolo':
+            outs = (locs, torch.randn(2, P, generator=g), confs)
+        else:
+            outs = (locs, confs)
+        gts = [O.synth_gt(i, 20, False, **case['gt_kw']) for i in case['gt_images']]
+        res = m.loss(tuple(o.to(dev) for o in outs), [q[0] for q in gts], [q[1] for q in gts])
+        assert set(res) == set(case['loss']), name
+        for k, want in case['loss'].items():
+            assert abs(float(res[k]) - want) <= 1e-4 * max(abs(want), 1e-6), (name, k, float(res[k]), want)
+
+
 # ----------------------------------------------------------------------------- full size
 
 def test_retinanet800_full_size(D, oracle, dev):
