@@ -2,18 +2,20 @@
 // Replaces torchvision.ops.batched_nms as called at src/utilities/predictor.py:55
 // and the per-detection Python loop of src/utilities/predictor.py:56-73.
 //
-// nms_segments   one workgroup per (image, class segment): stable descending sort
-//                of the segment (bitonic on 64-bit keys in LDS), boxes gathered into
-//                LDS in that order, then a blocked greedy sweep: for every 64-box
-//                chunk the 64x64 suppression words are built by all four waves, one
-//                wave resolves the chunk serially with readlane on the LDS-resident
-//                words, and the boxes it kept knock out later boxes in parallel
-//                (suppression bitmap in LDS).  Only kept boxes ever act as
-//                suppressors, exactly like the sequential CPU algorithm.
+// nms_segments   one workgroup (or, for thousands of short segments, one wave) per (image, class
+//                segment): stable descending sort of the segment on 64-bit keys held in registers,
+//                boxes gathered into LDS in that order, then a blocked greedy sweep: for every
+//                64-box chunk the mutual suppression words, a serial resolve by one wave, and the
+//                boxes it kept knock out later boxes (integer reject on quantised boxes first, the
+//                reference's fp32 test for what is left).  Only kept boxes ever act as
+//                suppressors, exactly like the sequential CPU algorithm.  A generic kernel covers
+//                presorted, very long and negative-threshold segments.
 // nms_scan       per image: offsets of the kept runs.
-// nms_merge      log2(S) stable merge levels (merge-path tiles staged in LDS) turn the
-//                per-class kept runs into one list per image in descending score order
-//                -- the order torchvision returns.
+// nms_merge      stable merge of the per-class kept runs into one list per image in descending
+//                score order -- the order torchvision returns: the first levels inside LDS, the
+//                rest as merge-path tiles.
+// pack           result rows (float64, src/utilities/predictor.py:60-73) and the compact message
+//                ranks exchange.
 //
 // IoU arithmetic follows torchvision's CPU kernel: areas (x2-x1)*(y2-y1),
 // inter / (area_i + area_j - inter) in fp32, suppressed iff (double)iou > threshold;
@@ -145,18 +147,6 @@ __device__ inline unsigned long long uniform64(unsigned long long v) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;
-}
-
-// v_min_f32 / v_max_f32 without the NaN-quieting copies fminf/fmaxf add in front of them.
-__device__ inline float vmin_raw(float a, float b) {
-    float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ inline float vmax_raw(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
 }
 
 __device__ inline float readlane_f(float v, int l) {

@@ -5,18 +5,22 @@
 // `argsort(descending=True).argsort() < top_k` rank trick (ssd300.py:370).
 //
 // The head output [B,P,C] (class innermost) is streamed from HBM ONCE on the fast path:
-//   select_sample   activates every sample_rate-th 64-anchor sub-tile and builds a 256-bin
-//                   histogram per (image,class) of the sampled scores above the threshold;
-//   select_plan     per (image,class): a score t_lo low enough that, with overwhelming
-//                   probability, at least top_k scores lie at or above it (or "stage all");
-//   select_scan     the one full pass: 64 anchors x C logits are staged in LDS (coalesced
-//                   16-byte loads), four lanes share an anchor row for the soft-max, every
-//                   score >= t_lo is appended to a block-local LDS list and flushed with ONE
-//                   global atomic per (block, class) into that pair's staging list;
+//   select_sample   activates every sample_rate-th 64-anchor sub-tile and writes the sampled
+//                   scores class-major;
+//   select_plan     per (image,class): the exact sample_m-th largest sampled score (LDS radix
+//                   select) = a score t_lo low enough that, with overwhelming probability, at
+//                   least top_k scores lie at or above it (or "stage all");
+//   select_scan     the one full pass: 64 anchors x C logits go HBM -> LDS by 16-byte LDS-DMA,
+//                   double buffered; four lanes share an anchor row for the soft-max; every
+//                   score >= t_lo is appended to the wave's own list (no atomics);
+//   select_bucket   counting sort of a scan workgroup's lists by class, one global atomic per
+//                   (workgroup, class) into that pair's staging list;
 //   select_check    verifies the guess (enough staged, not too many); pairs that fail are
 //                   handed to the exact two-pass fallback below and a flag is raised;
-//   select_finalize per (image,class): exact top_k of the staged keys by radix select in LDS,
+//   select_finalize per (image,class): exact top_k of the staged keys by radix select,
 //                   ordering by anchor index through an LDS bitmap + popcount scan, decode.
+// The focal-loss kernels at the end of the file stream the same tensor through the same
+// sub-tile machinery (training side).
 // Fallback (kernels exit at once unless the flag is up; also the only path for tiny P):
 //   select_materialize (fused activation only) writes the activated scores to the workspace,
 //   score_hist / select_kth / select_refine / select_emit find the exact boundary bin (or, on
