@@ -323,6 +323,29 @@ def test_select_ties_and_degenerate_inputs(D, oracle, dev):
     check_select((pb, ps, pc), oracle_select(O, s[:1], locs[:1], anchors, 0, 1, 0, 0.01, 50, fast=False))
 
 
+def test_select_at_the_documented_limits(D, oracle, dev):
+    """Widest class counts (C = 129 with 128 selected classes; C = 200 selecting the upper 100), largest
+    top_k (4096) on a sampled-path size, and a fused activation at C = 200."""
+    O = oracle
+    g = torch.Generator().manual_seed(17)
+    P = 20000
+    anchors = torch.rand(P, 4, generator=g) * 0.5 + 0.2
+    for C, cb, k in ((129, 1, 300), (200, 100, 64), (3, 1, 4096), (2, 1, 3000)):
+        s = torch.rand(2, P, C, generator=g)
+        locs = torch.randn(2, P, 4, generator=g)
+        _, pb, ps, pc = hip_select(D, dev, s, locs, anchors, D.ops.DECODE_CXCYWH, cb, 0, 0.05, k)
+        check_select((pb, ps, pc), oracle_select(O, s, locs, anchors, 0, cb, 0, 0.05, k))
+    logits = torch.randn(1, P, 200, generator=g) * 2
+    locs = torch.randn(1, P, 4, generator=g)
+    act = D.ops.activate_scores(logits.to(dev), None, D.ops.ACT_SOFTMAX).cpu()
+    assert torch.allclose(act, torch.softmax(logits, -1), rtol=2e-6, atol=1e-9)
+    c = D.ops.select_decode(logits.to(dev), locs.to(dev), anchors.to(dev), D.ops.DECODE_CXCYWH, 150, 0, 0.001, 100,
+                            activation=D.ops.ACT_SOFTMAX)
+    n = int(c.counts[0])
+    want = oracle_select(O, act, locs, anchors, 0, 150, 0, 0.001, 100)
+    check_select(([c.boxes[0, :n].cpu()], [c.scores[0, :n].cpu()], [c.class_ids[0, :n].cpu()]), want)
+
+
 def torch_activation(m, outputs):
     """The reference's activation in plain PyTorch (ssd300.py:354, fcos.py:314, yolov3.py:298-300)."""
     if m.activation == 1:
