@@ -1,0 +1,151 @@
+"""Randomised parity soak of the HIP path against the CPU oracle (development aid, run on the GPU box):
+
+    python tools/soak.py [seconds per category] [seed]
+
+Draws shapes, thresholds and score distributions at random for NMS, selection and assignment and compares
+every result with the oracle (bit-exact indices / labels / keep lists, 1e-5 on coordinates).  Prints a
+progress line per category and stops at the first mismatch with the case that produced it.
+"""
+import os
+import subprocess
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+subprocess.check_call(['make', '-s', '-C', os.path.join(REPO, 'oracle')])
+
+import object_detection_amd as D  # noqa: E402
+from oracle import boxops_oracle as O  # noqa: E402
+
+dev = torch.device('cuda', 0)
+BUDGET = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+
+
+def close(a, b, rtol=1e-5):
+    if a.shape != b.shape:
+        return False
+    if a.numel() == 0:
+        return True
+    scale = b.abs().amax(dim=-1, keepdim=True).clamp(min=1e-30)
+    return bool(((a - b).abs() <= rtol * scale + 1e-7).all())
+
+
+def rnd_boxes(g, n, spread, size):
+    c = spread * torch.rand(n, 2, generator=g)
+    wh = 0.01 + size * torch.rand(n, 2, generator=g)
+    return torch.cat([c - wh / 2, c + wh / 2], 1)
+
+
+def soak_nms(g):
+    n = int(torch.randint(1, 3500, (1,), generator=g))
+    ncls = int(torch.randint(1, 40, (1,), generator=g))
+    thr = [0.0, 0.3, 0.45, 0.5, 0.7, 0.9][int(torch.randint(0, 6, (1,), generator=g))]
+    spread = [0.05, 0.3, 1.0, 30.0][int(torch.randint(0, 4, (1,), generator=g))]
+    size = [0.02, 0.2, 0.8][int(torch.randint(0, 3, (1,), generator=g))]
+    boxes = rnd_boxes(g, n, spread, size)
+    if int(torch.randint(0, 3, (1,), generator=g)) == 0:          # clusters of near-duplicates
+        base = boxes[torch.randint(0, max(n // 20, 1), (n,), generator=g)]
+        boxes = base + 0.01 * size * torch.randn(n, 4, generator=g)
+    scores = torch.rand(n, generator=g)
+    if int(torch.randint(0, 2, (1,), generator=g)):
+        scores = (scores * 32).round() / 32
+    idxs = torch.randint(0, ncls, (n,), generator=g)
+    want = O.batched_nms(boxes, scores, idxs, thr)
+    got = D.batched_nms(boxes.to(dev), scores.to(dev), idxs.to(dev), thr).cpu()
+    return torch.equal(got, want), dict(kind='nms', n=n, ncls=ncls, thr=thr, spread=spread, size=size)
+
+
+def soak_select(g):
+    P = int(torch.randint(50, 60000, (1,), generator=g))
+    C = int(torch.randint(2, 40, (1,), generator=g))
+    k = int(torch.randint(1, 1500, (1,), generator=g))
+    B = int(torch.randint(1, 4, (1,), generator=g))
+    act = int(torch.randint(0, 4, (1,), generator=g))
+    thr = [0.01, 0.05, 0.3][int(torch.randint(0, 3, (1,), generator=g))]
+    logits = torch.randn(B, P, C, generator=g) * float(torch.rand(1, generator=g) * 4 + 0.2)
+    if int(torch.randint(0, 3, (1,), generator=g)) == 0:
+        logits = (logits * 2).round() / 2                         # heavy ties
+    locs = torch.randn(B, P, 4, generator=g)
+    anchors = torch.rand(P, 4, generator=g) * 0.5 + 0.2
+    extra = torch.randn(B, P, generator=g) if act in (2, 3) else None
+    cb = 0 if act == 3 else 1
+    if act == 0:
+        scores_in = torch.rand(B, P, C, generator=g)
+        act_scores = scores_in
+    else:
+        scores_in = logits
+        act_scores = D.ops.activate_scores(logits.to(dev), None if extra is None else extra.to(dev), act).cpu()
+        ref = torch.softmax(logits, -1) if act in (1, 2) else torch.sigmoid(logits)
+        if extra is not None:
+            ref = ref * torch.sigmoid(extra)[..., None]
+        if not torch.allclose(act_scores, ref, rtol=3e-6, atol=1e-9):
+            return False, dict(kind='activation', P=P, C=C, act=act)
+    c = D.ops.select_decode(scores_in.to(dev), locs.to(dev), anchors.to(dev), D.ops.DECODE_CXCYWH, cb, 0, thr, k,
+                            activation=act, extra=None if extra is None else extra.to(dev))
+    counts = c.counts.cpu().tolist()
+    ok = True
+    for b in range(B):
+        wb, ws, wc = O.select_decode_fast(locs[b], act_scores[b], anchors, thr, k, 'cxcywh', cb, 0)
+        n = counts[b]
+        ok = ok and n == ws.numel() and torch.equal(c.scores[b, :n].cpu(), ws) and torch.equal(c.class_ids[b, :n].cpu(), wc) \
+            and close(c.boxes[b, :n].cpu(), wb)
+    return ok, dict(kind='select', P=P, C=C, k=k, B=B, act=act, thr=thr)
+
+
+def soak_assign(g):
+    fam = int(torch.randint(0, 3, (1,), generator=g))
+    B = int(torch.randint(1, 6, (1,), generator=g))
+    gts = []
+    for _ in range(B):
+        G = int(torch.randint(1, 90, (1,), generator=g))
+        c = 0.1 + 0.8 * torch.rand(G, 2, generator=g)
+        wh = 0.01 + 0.6 * torch.rand(G, 2, generator=g)
+        lab = torch.randint(1, 21, (G,), generator=g)
+        gts.append((torch.cat([c, wh], 1), lab))
+    if fam == 0:
+        m = D.SSD300(20)
+        got = m.assign([q[0] for q in gts], [q[1] for q in gts], dev)
+        want = O.assign_ssd(m.dboxes, [q[0] for q in gts], [q[1] for q in gts])
+    elif fam == 1:
+        m = D.RetinaNet(20, [32, 16, 8, 4, 2])
+        got = m.assign([q[0] for q in gts], [q[1] for q in gts], dev)
+        want = O.assign_retinanet(m.pboxes, [q[0] for q in gts], [q[1] for q in gts])
+    else:
+        m = D.FCOS(20, [32, 16, 8, 4, 2])
+        gb = [q[0] * 512.0 for q in gts]
+        got = m.assign(gb, [q[1] for q in gts], dev)
+        want = O.assign_fcos(m.points, m.regress_ranges, gb, [q[1] for q in gts])
+        ok = torch.equal(got[2].cpu(), want[2]) and torch.equal(got[3].cpu(), want[3]) and close(got[0].cpu(), want[0])
+        pos = want[2] > 0
+        ok = ok and torch.allclose(got[1].cpu()[pos], want[1][pos], rtol=1e-5, atol=1e-7)
+        return ok, dict(kind='assign_fcos', B=B)
+    ok = torch.equal(got[1].cpu(), want[1]) and torch.equal(got[2].cpu(), want[2]) and close(got[0].cpu(), want[0])
+    return ok, dict(kind='assign', fam=fam, B=B)
+
+
+def main():
+    for name, fn in (('nms', soak_nms), ('select', soak_select), ('assign', soak_assign)):
+        g = torch.Generator().manual_seed(SEED * 1000 + hash(name) % 997)
+        t0, n = time.time(), 0
+        last = t0
+        while time.time() - t0 < BUDGET:
+            state = g.get_state()
+            ok, case = fn(g)
+            n += 1
+            if not ok:
+                print('MISMATCH', name, case, 'generator state saved to gpurun_out/soak_fail.pt', flush=True)
+                os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
+                torch.save(dict(state=state, case=case, name=name), os.path.join(REPO, 'gpurun_out', 'soak_fail.pt'))
+                sys.exit(1)
+            if time.time() - last > 20:
+                print(f'{name}: {n} cases ok', flush=True)
+                last = time.time()
+        print(f'{name}: {n} cases ok in {time.time() - t0:.0f} s', flush=True)
+
+
+if __name__ == '__main__':
+    main()
