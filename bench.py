@@ -33,6 +33,8 @@ WORKLOADS = {
     # name: (family, ctor, B, C_stored, top_k, coco_like, gt_fmt, gt_scale)
     'retinanet800': dict(family='retina', B=16, C=81, top_k=1000, coco=True, fmt='cxcywh', scale=1.0,
                          make=lambda: D.RetinaNet(80, [100, 50, 25, 13, 7])),
+    'retinanet800_b512': dict(family='retina', B=512, C=81, top_k=1000, coco=True, fmt='cxcywh', scale=1.0,
+                              make=lambda: D.RetinaNet(80, [100, 50, 25, 13, 7])),
     'retinanet800_b128': dict(family='retina', B=128, C=81, top_k=1000, coco=True, fmt='cxcywh', scale=1.0,
                               make=lambda: D.RetinaNet(80, [100, 50, 25, 13, 7])),
     'ssd300': dict(family='ssd', B=8, C=21, top_k=200, coco=False, fmt='cxcywh', scale=1.0, make=lambda: D.SSD300(20)),

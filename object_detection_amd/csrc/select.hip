@@ -1081,9 +1081,21 @@ SelPlan make_plan(int64_t B, int64_t P, int64_t C, int64_t Cs, int top_k) {
     std::memset(&sp, 0, sizeof(sp));
     const double z = 4.5;
     sp.n_sub = (int)((P + SUB_ROWS - 1) / SUB_ROWS);
-    // one round of resident workgroups: a second, partly filled round would cost as much as a full one
+    // Whole rounds of resident workgroups: a partly filled round costs as much as a full one.  With gx
+    // workgroups per image the scan takes ceil(B*gx / resident) rounds of ceil(n_sub / gx) sub-tiles each;
+    // take the gx that minimises the product.
     const int64_t resident = scan_resident_workgroups(C);
-    int64_t spb = (B * sp.n_sub + resident - 1) / resident;
+    int64_t best_cost = -1, spb = sp.n_sub;
+    for (int64_t r = 1; r <= 8; ++r) {
+        int64_t gx = (r * resident) / (B > 0 ? B : 1);
+        if (gx < 1) gx = 1;
+        if (gx > sp.n_sub) gx = sp.n_sub;
+        const int64_t per = (sp.n_sub + gx - 1) / gx;
+        const int64_t gx2 = (sp.n_sub + per - 1) / per;
+        const int64_t rounds = (B * gx2 + resident - 1) / resident;
+        const int64_t cost = rounds * per;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; spb = per; }
+    }
     sp.subs_per_block = (int)(spb < 1 ? 1 : spb);
     sp.scan_gx = (sp.n_sub + sp.subs_per_block - 1) / sp.subs_per_block;
     if (P < 4096 || P > (1 << 24)) {                     // tiny inputs, or anchors beyond the 24-bit entry field
