@@ -77,6 +77,7 @@ class Workload:
         w = WORKLOADS[name]
         self.name, self.regime, self.w, self.dev = name, regime, w, dev
         self.exchange = None
+        self.exchange_root = 0          # the evaluator is one process (rank 0), as in the reference's test loop
         self.model = w['make']()
         m = self.model
         self.anchors_cpu = m._anchors_for_decode()
@@ -128,10 +129,10 @@ class Workload:
         keep, kc = ops.nms_candidates(c, 0.45)
         rows_ids, rows_vals, row_off = ops.pack_detections(c.boxes, c.scores, c.class_ids, keep, kc, self.ids, self.hw)
         if world > 1:
-            # the exchange step: this rank's detections as a compact message; the all-gather of the previous
+            # the exchange step: this rank's detections as a compact message; the gather of the previous
             # batch's messages starts now, on a side stream, and overlaps this batch's kernels
             if self.exchange is None:
-                self.exchange = RowExchange(keep_results=False)
+                self.exchange = RowExchange(keep_results=False, root=self.exchange_root)
                 self.hdr_rows = ops.wire_header_rows(self.B)
             wire = ops.pack_wire(c.boxes, c.scores, c.class_ids, keep, kc, self.ids, self.hw, self.B)
             self.exchange.submit(wire, self.B, self.hdr_rows)
@@ -190,6 +191,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle timing (profiling runs)')
     ap.add_argument('--graph', action='store_true',
                     help='N=1 only: capture one step in a HIP graph and replay it in the timed region (launch-bound workloads)')
+    ap.add_argument('--exchange', default='root', choices=['root', 'all'],
+                    help='N>1: detections are gathered to rank 0 (one evaluator process) or to every rank')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -211,6 +214,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     wl = Workload(args.workload, args.regime, rank, dev)
+    wl.exchange_root = 0 if args.exchange == 'root' else None
     B, P, C = wl.B, wl.P, wl.C
 
     def barrier():
@@ -331,7 +335,7 @@ def main():
             'launch': 'hip-graph replay' if graph is not None else 'stream',
             'config': {'workload': f'{args.workload} {args.regime}: B={B}/GPU P={P} C={C} top_k={wl.top_k} conf>0.01 nms=0.45',
                        'images_per_gpu': B, 'global_batch': world * B, 'candidates_per_image': n_cand,
-                       'kept_per_image': n_keep, 'gt_per_image': G_mean, 'parallelism': f'image-sharded x{world}'},
+                       'kept_per_image': n_keep, 'gt_per_image': G_mean, 'parallelism': f'image-sharded x{world}', 'exchange': ('none' if world == 1 else ('gather to rank 0' if args.exchange == 'root' else 'all-gather'))},
             'roofline': roofline,
             'roofline_streaming': streaming,
             'cpu_baseline': cpu,

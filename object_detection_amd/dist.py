@@ -83,11 +83,18 @@ class RowExchange:
     side stream, so its transfer overlaps the kernels of the current batch and the host never waits for
     the batch in flight.  finish() starts the last gather and waits for all of them.  Two collectives per
     batch: the counts (to agree on the padded length) and the messages.  Works on gloo/CPU tensors too
-    (no streams there)."""
+    (no streams there).
 
-    def __init__(self, group=None, keep_results: bool = True):
+    root=None: every rank receives every message (all-gather).  root=r: only global rank r receives them
+    (gather) -- what a single evaluator process needs (src/test.py:98-99 builds one list in one process);
+    the other ranks only send, so the traffic per batch is one message per link instead of world of them.
+    On those ranks the gathered buffer of a batch is None."""
+
+    def __init__(self, group=None, keep_results: bool = True, root=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.root = root
+        self.rank = dist.get_rank() if self.world > 1 else 0
         # RCCL moves device buffers; any other backend (gloo rehearsals) gets the message staged on the host
         self.device_collectives = self.world > 1 and dist.get_backend(group) == 'nccl'
         self.keep_results = keep_results
@@ -147,16 +154,24 @@ class RowExchange:
             else:                                  # another rank has more rows than this buffer holds
                 send = torch.zeros((rows, 6), dtype=torch.int32, device=wire.device)
                 send[:wire.shape[0]] = wire
-            out = torch.empty((self.world, rows, 6), dtype=torch.int32, device=wire.device)
-            work = dist.all_gather_into_tensor(out.view(self.world * rows, 6), send, group=self.group, async_op=True)
+            if self.root is None:
+                out = torch.empty((self.world, rows, 6), dtype=torch.int32, device=wire.device)
+                work = dist.all_gather_into_tensor(out.view(self.world * rows, 6), send, group=self.group, async_op=True)
+            else:
+                send = send.contiguous()
+                out = parts = None
+                if self.rank == self.root:
+                    out = torch.empty((self.world, rows, 6), dtype=torch.int32, device=wire.device)
+                    parts = list(out.unbind(0))
+                work = dist.gather(send, parts, dst=self.root, group=self.group, async_op=True)
             if wire.is_cuda:
                 wire.record_stream(self.comm)
-        self.flying.append((work, out, header_rows, counts))
+        self.flying.append((work, out, header_rows, counts, send))
         while len(self.flying) > 2:                # retire old gathers (they finished long ago)
             self._retire(self.flying.pop(0))
 
     def _retire(self, f):
-        work, out, header_rows, counts = f
+        work, out, header_rows, counts = f[:4]
         if work is not None:
             work.wait()
         if self.keep_results:
@@ -178,5 +193,7 @@ class RowExchange:
 def unpack_gathered(batch) -> Tuple[torch.Tensor, torch.Tensor]:
     """(out [world, rows, 6], header_rows, counts) of one batch -> rows of all ranks in rank order."""
     out, header_rows, counts = batch
+    if out is None:
+        raise ValueError('this rank did not receive the batch (RowExchange(root=...) delivers to the root only)')
     parts = [unpack_wire(out[r], header_rows) for r in range(out.shape[0])]
     return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])

@@ -51,8 +51,17 @@ def _workspace(device, nbytes: int, tag: str) -> torch.Tensor:
     return ws
 
 
+def _dense(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[torch.Tensor]:
+    """The dtype, dense layout and 16-byte alignment the kernels assume; a no-op for a freshly allocated
+    tensor of the right type, a copy for a strided view or a slice that starts off a 16-byte boundary."""
+    if t is None:
+        return None
+    t = t.to(dtype).contiguous()
+    return t.clone() if t.data_ptr() % 16 else t
+
+
 def _f32(t: torch.Tensor, device) -> torch.Tensor:
-    return t.to(device=device, dtype=torch.float32).contiguous()
+    return _dense(t.to(device=device))
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -142,7 +151,11 @@ def assign_anchor(anchors: torch.Tensor, gt_boxes: torch.Tensor, gt_labels: torc
                   total_gt: int, mode: int, thr_lo: float, thr_hi: float, want_best: bool = False):
     """-> target_locs [B,P,4] f32, target_labels [B,P] i64, matched [B,P] i64 (, best_anchor [sum G] i64)."""
     dev = anchors.device
+    anchors, gt_boxes = _dense(anchors), _dense(gt_boxes)
+    gt_labels, gt_offsets = _dense(gt_labels, torch.int64), _dense(gt_offsets, torch.int32)
     B, P = gt_offsets.numel() - 1, anchors.shape[0]
+    if gt_boxes.shape[0] < total_gt or gt_labels.numel() < total_gt:
+        raise ValueError('assign_anchor: fewer ground-truth rows than total_gt')
     locs = torch.empty((B, P, 4), dtype=torch.float32, device=dev)
     labels = torch.empty((B, P), dtype=torch.int64, device=dev)
     matched = torch.empty((B, P), dtype=torch.int64, device=dev)
@@ -161,7 +174,11 @@ def assign_anchor(anchors: torch.Tensor, gt_boxes: torch.Tensor, gt_labels: torc
 def assign_fcos(points: torch.Tensor, ranges: torch.Tensor, gt_boxes, gt_labels, gt_offsets, total_gt: int):
     """-> target_locs [B,P,4] (l,r,t,b), target_cents [B,P], target_labels [B,P], matched [B,P]."""
     dev = points.device
+    points, ranges, gt_boxes = _dense(points), _dense(ranges), _dense(gt_boxes)
+    gt_labels, gt_offsets = _dense(gt_labels, torch.int64), _dense(gt_offsets, torch.int32)
     B, P = gt_offsets.numel() - 1, points.shape[0]
+    if gt_boxes.shape[0] < total_gt or gt_labels.numel() < total_gt or ranges.shape[0] != P:
+        raise ValueError('assign_fcos: table or ground-truth sizes do not fit')
     locs = torch.empty((B, P, 4), dtype=torch.float32, device=dev)
     cents = torch.empty((B, P), dtype=torch.float32, device=dev)
     labels = torch.empty((B, P), dtype=torch.int64, device=dev)
@@ -188,6 +205,7 @@ class Candidates:
 def activate_scores(head: torch.Tensor, extra: Optional[torch.Tensor], activation: int) -> torch.Tensor:
     """The activated scores [B,P,C] exactly as select_decode computes them internally."""
     dev = head.device
+    head, extra = _dense(head), _dense(extra)
     B, P, C = head.shape
     out = torch.empty_like(head)
     with torch.cuda.device(dev):
@@ -203,7 +221,12 @@ def select_decode(scores: torch.Tensor, locs: torch.Tensor, anchors: torch.Tenso
     """scores: [B,P,C] activated scores (activation == ACT_NONE) or raw head output to be activated in
     the kernel; extra: [B,P] centerness / objectness logits for the activations that use them."""
     dev = scores.device
+    if not scores.is_cuda:
+        raise _lib.DetboxError('select_decode runs on a ROCm device only')
+    scores, locs, anchors, extra = _dense(scores), _dense(locs.to(dev)), _dense(anchors.to(dev)), _dense(None if extra is None else extra.to(dev))
     B, P, C = scores.shape
+    if locs.shape != (B, P, 4) or anchors.shape[0] != P or (extra is not None and extra.shape != (B, P)):
+        raise ValueError(f'select_decode: shapes {tuple(scores.shape)}, {tuple(locs.shape)}, {tuple(anchors.shape)} do not fit')
     S = C - class_begin
     stride = S * top_k
     out_boxes = torch.empty((B, stride, 4), dtype=torch.float32, device=dev)
@@ -226,7 +249,10 @@ def nms_segments(boxes: torch.Tensor, scores: torch.Tensor, seg_offsets: torch.T
                  max_segment: int = 0, presorted: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """boxes [B,stride,4], scores [B,stride], seg_offsets [B,S+1] -> keep [B,stride] i64, keep_counts [B] i32."""
     dev = boxes.device
+    boxes, scores, seg_offsets = _dense(boxes), _dense(scores), _dense(seg_offsets, torch.int32)
     B, stride = scores.shape
+    if boxes.shape != (B, stride, 4) or seg_offsets.shape[0] != B:
+        raise ValueError(f'nms_segments: shapes {tuple(boxes.shape)}, {tuple(scores.shape)}, {tuple(seg_offsets.shape)} do not fit')
     S = seg_offsets.shape[1] - 1
     keep = torch.empty((B, stride), dtype=torch.int64, device=dev)
     kc = torch.empty((B,), dtype=torch.int32, device=dev)
@@ -248,7 +274,12 @@ def pack_detections(boxes, scores, class_ids, keep, keep_counts, image_ids: torc
     """-> rows_ids [B*stride,2] i64, rows_vals [B*stride,5] f64, row_offsets [B+1] i32 (rows beyond
     row_offsets[B] are unused)."""
     dev = boxes.device
+    boxes, scores, class_ids, keep = _dense(boxes), _dense(scores), _dense(class_ids, torch.int64), _dense(keep, torch.int64)
+    keep_counts, image_sizes = _dense(keep_counts, torch.int32), _dense(image_sizes.to(dev), torch.int32)
+    image_ids = _dense(image_ids.to(dev), torch.int64)
     B, stride = scores.shape
+    if boxes.shape != (B, stride, 4) or keep.shape != (B, stride) or image_ids.numel() != B or image_sizes.shape != (B, 2):
+        raise ValueError('pack_detections: shapes do not fit')
     rows_ids = torch.empty((B * stride, 2), dtype=torch.int64, device=dev)
     rows_vals = torch.empty((B * stride, 5), dtype=torch.float64, device=dev)
     row_off = torch.empty((B + 1,), dtype=torch.int32, device=dev)
@@ -268,7 +299,7 @@ class _FocalLossSum(torch.autograd.Function):
     def forward(ctx, logits, labels, alpha, gamma):
         dev = logits.device
         C = logits.shape[-1]
-        x = logits.detach().reshape(-1, C).to(torch.float32).contiguous()
+        x = _dense(logits.detach().reshape(-1, C))
         t = labels.reshape(-1).to(device=dev, dtype=torch.int64).contiguous()
         out = torch.empty((), dtype=torch.float64, device=dev)
         with torch.cuda.device(dev):
@@ -309,7 +340,14 @@ def pack_wire(boxes, scores, class_ids, keep, keep_counts, image_ids: torch.Tens
     """-> wire [header_rows + B*stride, 6] int32: the kept detections of this rank as a compact message
     (see detbox_pack_wire); `dist.unpack_wire` turns gathered messages back into result rows."""
     dev = boxes.device
+    boxes, scores, class_ids, keep = _dense(boxes), _dense(scores), _dense(class_ids, torch.int64), _dense(keep, torch.int64)
+    keep_counts, image_sizes = _dense(keep_counts, torch.int32), _dense(image_sizes.to(dev), torch.int32)
+    image_ids = _dense(image_ids.to(dev), torch.int64)
     B, stride = scores.shape
+    if boxes.shape != (B, stride, 4) or keep.shape != (B, stride) or image_ids.numel() != B or image_sizes.shape != (B, 2):
+        raise ValueError('pack_wire: shapes do not fit')
+    if B > images_cap:
+        raise ValueError('pack_wire: more images than images_cap')
     wire = torch.empty((wire_header_rows(images_cap) + B * stride, 6), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().detbox_pack_wire(_ptr(boxes), _ptr(scores), _ptr(class_ids), _ptr(keep),

@@ -3,6 +3,7 @@ single-process result order."""
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -80,7 +81,7 @@ def _fake_dets(image_index: int):
     return (torch.randint(1, 81, (n,), generator=g), torch.rand(n, 4, generator=g), torch.rand(n, generator=g))
 
 
-def _exchange_worker(rank, world, port, batches, per_rank, q):
+def _exchange_worker(rank, world, port, batches, per_rank, q, root=None):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     import sys
@@ -88,19 +89,20 @@ def _exchange_worker(rank, world, port, batches, per_rank, q):
     from helpers import wire_from_rows
     from object_detection_amd.dist import RowExchange, unpack_gathered
     hdr = (2 + (per_rank + 1) + 4 * per_rank + 5) // 6
-    ex = RowExchange()
+    ex = RowExchange(root=root)
     for k in range(batches):
         imgs = [k * world * per_rank + rank * per_rank + i for i in range(per_rank - (1 if (rank == 1 and k == 1) else 0))]
         dets = [_fake_dets(i) for i in imgs]
         wire = wire_from_rows(dets, [(1 << 33) + i for i in imgs], [(100 + i, 200 + i) for i in imgs], hdr)
         ex.submit(wire, per_rank, hdr)
-    got = [unpack_gathered(bt) for bt in ex.finish()]
+    got = [unpack_gathered(bt) for bt in ex.finish() if bt[0] is not None]
     q.put((rank, [(a.numpy(), b.numpy()) for a, b in got]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_row_exchange_pipelined_world2():
+@pytest.mark.parametrize('root', [None, 1])
+def test_row_exchange_pipelined_world2(root):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from helpers import rows_from_detections
@@ -108,14 +110,17 @@ def test_row_exchange_pipelined_world2():
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, batches, per_rank, q)) for r in range(world)]
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, batches, per_rank, q, root)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for _, per_batch in got:
+    for rank_, per_batch in got:
+        if root is not None and rank_ != root:          # gather to the root: the other ranks only send
+            assert per_batch == []
+            continue
         assert len(per_batch) == batches
         for k, (gids, gvals) in enumerate(per_batch):
             imgs = []

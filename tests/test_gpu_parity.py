@@ -762,3 +762,64 @@ def test_bench_workload_properties_full_batch(D, oracle, dev):
     # assignment: every ground-truth box got its best anchor labelled positive or ignored, never background
     locs, labels, matched = targets[:3]
     assert labels.shape == (B, wl.P) and int((labels > 0).sum()) > 0
+
+
+def test_batch_beyond_2_to_31_elements_is_batch_invariant(D, oracle, dev):
+    """A head output of more than 2^31 floats (B=224 RetinaNet-800 images, 8.7 GB): every offset of the
+    streaming pass must be 64-bit.  Each image is independent, so the first and the last image of the big
+    batch must give bit for bit what they give alone, and the focal sum of the big batch is linear."""
+    m = D.RetinaNet(80, [100, 50, 25, 13, 7])
+    P, C, B = m.pboxes.shape[0], 81, 224
+    assert B * P * C > 2 ** 31
+    g = torch.Generator(device=dev).manual_seed(77)
+    confs = torch.randn(B, P, C, generator=g, device=dev)
+    locs = torch.randn(B, P, 4, generator=g, device=dev)
+    anchors = m._table(m._anchors_for_decode(), dev)
+
+    def run(lo, hi):
+        c = D.ops.select_decode(confs[lo:hi], locs[lo:hi], anchors, D.ops.DECODE_CXCYWH, 1, 0, 0.01, 1000,
+                                activation=D.ops.ACT_SOFTMAX)
+        keep, kc = D.ops.nms_candidates(c, 0.45)
+        return c, keep, kc
+
+    c, keep, kc = run(0, B)
+    assert bool((kc >= 0).all())
+    for b in (0, B - 1):
+        c1, keep1, kc1 = run(b, b + 1)
+        n = int(c1.counts[0])
+        assert n == int(c.counts[b]) and n > 0
+        assert torch.equal(c.seg_offsets[b], c1.seg_offsets[0])
+        assert torch.equal(c.scores[b, :n], c1.scores[0, :n]) and torch.equal(c.class_ids[b, :n], c1.class_ids[0, :n])
+        assert torch.equal(c.boxes[b, :n], c1.boxes[0, :n])
+        k = int(kc1[0])
+        assert k == int(kc[b]) and torch.equal(keep[b, :k], keep1[0, :k])
+    del c, keep, kc
+    # fused focal loss over the same tensor: the sum over the batch equals the sum of two halves (float64 accumulation)
+    labels = torch.randint(0, C, (B, P), generator=g, device=dev)
+    whole = D.ops.focal_loss_sum(confs.reshape(-1, C), labels.reshape(-1), 0.25, 2.0)
+    h = B // 2
+    halves = D.ops.focal_loss_sum(confs[:h].reshape(-1, C), labels[:h].reshape(-1), 0.25, 2.0) + \
+        D.ops.focal_loss_sum(confs[h:].reshape(-1, C), labels[h:].reshape(-1), 0.25, 2.0)
+    assert abs(float(whole) - float(halves)) <= 1e-9 * abs(float(halves))      # float64 sums, different order
+
+
+def test_ops_accept_views_and_other_dtypes(D, oracle, dev):
+    """The host layer brings strided views, slices off a 16-byte boundary and other dtypes into the dense
+    fp32 layout the kernels read; results equal those of the dense call."""
+    g = torch.Generator().manual_seed(5)
+    B, P, C = 3, 5001, 7                                     # P*C odd: image 1 starts 4 bytes off a 16-byte boundary
+    scores = torch.rand(B, P, C, generator=g).to(dev)
+    locs = torch.randn(B, P, 4, generator=g).to(dev)
+    anchors = (torch.rand(P, 4, generator=g) * 0.5 + 0.2).to(dev)
+    ref = D.ops.select_decode(scores, locs, anchors, D.ops.DECODE_CXCYWH, 1, 0, 0.3, 50)
+    views = D.ops.select_decode(scores.permute(2, 0, 1).contiguous().permute(1, 2, 0).double(), locs.double(),
+                                anchors.cpu(), D.ops.DECODE_CXCYWH, 1, 0, 0.3, 50)
+    one = D.ops.select_decode(scores[1:2], locs[1:2], anchors, D.ops.DECODE_CXCYWH, 1, 0, 0.3, 50)
+    assert scores[1:2].data_ptr() % 16 != 0
+    n = int(ref.counts[1])
+    assert torch.equal(ref.counts, views.counts) and torch.equal(ref.scores[1, :n], views.scores[1, :n])
+    assert torch.equal(ref.boxes[1, :n], views.boxes[1, :n])
+    assert int(one.counts[0]) == n and torch.equal(one.boxes[0, :n], ref.boxes[1, :n])
+    keep_a, kc_a = D.ops.nms_candidates(ref, 0.45)
+    keep_b, kc_b = D.ops.nms_segments(ref.boxes.double(), ref.scores.double(), ref.seg_offsets.long(), 0.45, max_segment=50)
+    assert torch.equal(kc_a, kc_b) and torch.equal(keep_a[1, :int(kc_a[1])], keep_b[1, :int(kc_b[1])])
