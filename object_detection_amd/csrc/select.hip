@@ -480,10 +480,37 @@ __global__ __launch_bounds__(256) void select_plan_kernel(const float *__restric
                 const uint32_t suf = suffix_scan64(t, lane);
                 uint32_t digit, above, nd;
                 find_kth_bin(q, suf, t, lane, s_rem, digit, above, nd);
-                if (lane == 0) { s_pref = pref | (digit << shift); s_rem -= above; }
+                if (lane == 0) { s_pref = pref | (digit << shift); s_rem -= above; s_total = nd; s_max = 0u; }
             }
             __syncthreads();
             width = shift;
+            const uint32_t nd = s_total;
+            if (width > 0 && nd <= 256u) {
+                // Few keys are left in the chosen bin: gather them into the histogram array and rank them by
+                // counting, instead of sweeping all the keys once more per remaining digit.
+                const uint32_t want = s_pref >> width, rem = s_rem;
+                uint32_t nf = 0;
+                for (int i = tid; i < sp.ns_cap; i += 256) {
+                    const uint32_t k = s_key[i];
+                    nf += (k != 0u && (k >> width) == want);
+                }
+                uint32_t pos = nf ? atomicAdd(&s_max, nf) : 0u;
+                if (nf)
+                    for (int i = tid; i < sp.ns_cap; i += 256) {
+                        const uint32_t k = s_key[i];
+                        if (k != 0u && (k >> width) == want) s_h[pos++] = k;
+                    }
+                __syncthreads();
+                const uint32_t mine_k = tid < (int)nd ? s_h[tid] : 0u;
+                uint32_t rk = 0;
+                for (uint32_t j = 0; j < nd; ++j) {
+                    const uint32_t v = s_h[j];
+                    rk += (v > mine_k || (v == mine_k && j < (uint32_t)tid));
+                }
+                if (tid < (int)nd && rk == rem - 1u) s_pref = mine_k;       // rem <= nd: exactly one thread
+                __syncthreads();
+                width = 0;
+            }
         }
         dmin = s_pref;
     }
