@@ -57,4 +57,22 @@ __device__ __host__ inline uint32_t bits_from_okey(uint32_t k) {
     return (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
 }
 
+// Workgroups are dealt to the eight XCDs round-robin by linear workgroup id, and every XCD has an L2 of
+// its own.  For a grid (tiles, images) this returns the (tile, image) this workgroup should work on so that
+// all the workgroups of one image run on one XCD and that image's rows are fetched into one L2 only.
+// A bijection of the grid onto itself; the identity when the number of images is not a multiple of 8.
+struct TileOfImage { int x, y; };
+__device__ inline TileOfImage xcd_affine_tile() {
+    TileOfImage t;
+    t.x = (int)blockIdx.x; t.y = (int)blockIdx.y;
+    const unsigned T = gridDim.x, B = gridDim.y;
+    if ((B & 7u) == 0u) {
+        const unsigned L = blockIdx.x + T * blockIdx.y;
+        const unsigned idx = L >> 3;
+        t.y = (int)((L & 7u) + 8u * (idx / T));
+        t.x = (int)(idx % T);
+    }
+    return t;
+}
+
 }  // namespace detbox

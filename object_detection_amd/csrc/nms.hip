@@ -831,8 +831,9 @@ __global__ __launch_bounds__(256) void pack_detections_kernel(
     const int64_t *__restrict__ image_ids, const int32_t *__restrict__ image_sizes, int B, long long stride,
     int64_t *__restrict__ rows_ids, double *__restrict__ rows_vals, int32_t *__restrict__ row_offsets) {
     __shared__ int s_red[256];
-    const int b = blockIdx.y;
-    if (blockIdx.x != 0 && (int)(blockIdx.x * blockDim.x) >= keep_counts[b]) return;     // no rows here
+    const TileOfImage wg = xcd_affine_tile();            // the gathers of one image stay in one L2
+    const int b = wg.y, bx_ = wg.x;
+    if (bx_ != 0 && (int)(bx_ * blockDim.x) >= keep_counts[b]) return;     // no rows here
     int acc = 0;
     for (int i = threadIdx.x; i < b; i += blockDim.x) acc += max(keep_counts[i], 0);
     s_red[threadIdx.x] = acc;
@@ -843,14 +844,14 @@ __global__ __launch_bounds__(256) void pack_detections_kernel(
     }
     const int row0 = s_red[0];
     const int n = max(keep_counts[b], 0);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (bx_ == 0 && threadIdx.x == 0) {
         row_offsets[b] = row0;
         if (b == B - 1) row_offsets[B] = row0 + n;
     }
     // rows of this block are built in LDS and leave as contiguous 8-byte streams
     __shared__ double s_vals[256 * 5];
     __shared__ int64_t s_ids[256 * 2];
-    const int t0 = blockIdx.x * blockDim.x;
+    const int t0 = bx_ * blockDim.x;
     if (t0 >= n) return;
     const int nb = min(256, n - t0);
     const int t = t0 + threadIdx.x;
@@ -887,9 +888,10 @@ __global__ __launch_bounds__(256) void pack_wire_kernel(
     int hdr_rows, uint32_t *__restrict__ wire) {
     __shared__ int s_red[256];
     __shared__ uint32_t s_rows[256 * 6];
-    const int b = blockIdx.y;
+    const TileOfImage wg = xcd_affine_tile();
+    const int b = wg.y, bx_ = wg.x;
     const int n = max(keep_counts[b], 0);
-    if (blockIdx.x != 0 && (int)(blockIdx.x * blockDim.x) >= n) return;
+    if (bx_ != 0 && (int)(bx_ * blockDim.x) >= n) return;
     int acc = 0;
     for (int i = threadIdx.x; i < b; i += blockDim.x) acc += max(keep_counts[i], 0);
     s_red[threadIdx.x] = acc;
@@ -899,7 +901,7 @@ __global__ __launch_bounds__(256) void pack_wire_kernel(
         __syncthreads();
     }
     const int row0 = s_red[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (bx_ == 0 && threadIdx.x == 0) {
         wire[2 + b] = (uint32_t)row0;
         const unsigned long long id = (unsigned long long)image_ids[b];
         wire[2 + (B + 1) + 2 * b] = (uint32_t)id;
@@ -908,7 +910,7 @@ __global__ __launch_bounds__(256) void pack_wire_kernel(
         wire[2 + (B + 1) + 2 * B + 2 * b + 1] = (uint32_t)image_sizes[2 * b + 1];
         if (b == B - 1) { wire[0] = (uint32_t)(row0 + n); wire[1] = (uint32_t)B; wire[2 + B] = (uint32_t)(row0 + n); }
     }
-    const int t0 = blockIdx.x * blockDim.x;
+    const int t0 = bx_ * blockDim.x;
     if (t0 >= n) return;
     const int nb = min(256, n - t0);
     const int t = t0 + threadIdx.x;

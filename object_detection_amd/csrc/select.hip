@@ -916,7 +916,8 @@ __global__ __launch_bounds__(256) void select_finalize_kernel(
     __shared__ unsigned long long s_lo, s_hi, s_cut;
     __shared__ uint32_t s_rem, s_state;
     __shared__ uint32_t s_wsum[4];
-    const int ci = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const TileOfImage wg = xcd_affine_tile();         // the classes of one image share an L2: its locs are gathered once
+    const int ci = wg.x, b = wg.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const size_t bc = (size_t)b * sp.Cs + ci;
     const int n_sel = (int)rules[bc].n_sel;
