@@ -161,7 +161,7 @@ __device__ inline unsigned long long readlane64(unsigned long long v, int l) {
 
 __global__ __launch_bounds__(NMS_BLOCK) void nms_segments_generic_kernel(
     const float4 *__restrict__ boxes, const float *__restrict__ scores, const int32_t *__restrict__ seg_off,
-    NmsParams np, float2 *__restrict__ kept, int32_t *__restrict__ kcount, int32_t *__restrict__ err) {
+    NmsParams np, float2 *__restrict__ kept, int32_t *__restrict__ kcount) {
     extern __shared__ unsigned long long s_dyn[];
     const int s = blockIdx.x, b = blockIdx.y;
     const int32_t *so = seg_off + (size_t)b * (np.S + 1);
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_segments_generic_kernel(
     if (threadIdx.x == 0) kcount[(size_t)b * np.S + s] = 0;
     if (n <= 0) return;
     if (n > np.max_seg || (!np.presorted && n > DETBOX_NMS_MAX_SORT)) {
-        if (threadIdx.x == 0) err[b] = 1;
+        if (threadIdx.x == 0) kcount[(size_t)b * np.S + s] = -1;      // reported as keep_counts[b] = -1
         return;
     }
     // LDS carve-up (sizes fixed by the host from max_seg)
@@ -391,7 +391,7 @@ __host__ __device__ inline NmsFastLds nms_fast_lds(int max_seg, int n2, int blk)
 template <int JPT, int BLK>
 __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == 256 && JPT <= 4 ? 5 : 1))) void nms_segments_fast_kernel(
     const float4 *__restrict__ boxes, const float *__restrict__ scores, const int32_t *__restrict__ seg_off,
-    NmsParams np, float2 *__restrict__ kept, int32_t *__restrict__ kcount, int32_t *__restrict__ err) {
+    NmsParams np, float2 *__restrict__ kept, int32_t *__restrict__ kcount) {
     extern __shared__ unsigned long long s_dyn[];
     const int s = blockIdx.x, b = blockIdx.y;
     const int32_t *so = seg_off + (size_t)b * (np.S + 1);
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == 256 
     if (threadIdx.x == 0) kcount[(size_t)b * np.S + s] = 0;
     if (n <= 0) return;
     if (n > np.max_seg) {
-        if (threadIdx.x == 0) err[b] = 1;
+        if (threadIdx.x == 0) kcount[(size_t)b * np.S + s] = -1;      // reported as keep_counts[b] = -1
         return;
     }
     const NmsFastLds ld = nms_fast_lds(np.max_seg, np.n2, BLK);
@@ -664,17 +664,22 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == 256 
     }
 }
 
+// Exclusive scan of the kept counts of an image's segments; a negative count marks a segment the NMS
+// kernel refused (longer than max_segment) and turns the image's keep count into -1.
 __global__ __launch_bounds__(256) void nms_scan_kernel(const int32_t *__restrict__ kcount, int S,
-                                                       int32_t *__restrict__ koff, const int32_t *__restrict__ err,
-                                                       int32_t *__restrict__ keep_counts) {
+                                                       int32_t *__restrict__ koff, int32_t *__restrict__ keep_counts) {
     const int b = blockIdx.x;
     if (threadIdx.x != 0) return;
-    int acc = 0;
+    int acc = 0, bad = 0;
     const int32_t *kc = kcount + (size_t)b * S;
     int32_t *ko = koff + (size_t)b * (S + 1);
-    for (int s = 0; s < S; ++s) { ko[s] = acc; acc += kc[s]; }
+    for (int s = 0; s < S; ++s) {
+        const int c = kc[s];
+        ko[s] = acc;
+        if (c < 0) bad = 1; else acc += c;
+    }
     ko[S] = acc;
-    keep_counts[b] = err[b] ? -1 : acc;
+    keep_counts[b] = bad ? -1 : acc;
 }
 
 // One stable merge level: neighbouring runs (each `group` class segments of one image) are merged
@@ -929,7 +934,7 @@ __global__ __launch_bounds__(256) void pack_wire_kernel(
     for (int i = threadIdx.x; i < 6 * nb; i += 256) out[i] = s_rows[i];
 }
 
-struct NmsLayout { size_t kept_a, kept_b, kcount, koff, err, total, zero_off, zero_bytes; };
+struct NmsLayout { size_t kept_a, kept_b, kcount, koff, total; };
 
 NmsLayout nms_layout(int64_t B, int64_t stride, int64_t S) {
     NmsLayout L;
@@ -938,9 +943,6 @@ NmsLayout nms_layout(int64_t B, int64_t stride, int64_t S) {
     L.kept_b = off; off = align_up(off + (size_t)B * stride * sizeof(float2), 256);
     L.kcount = off; off = align_up(off + (size_t)B * S * sizeof(int32_t), 256);
     L.koff = off; off = align_up(off + (size_t)B * (S + 1) * sizeof(int32_t), 256);
-    L.zero_off = off;
-    L.err = off; off = align_up(off + (size_t)B * sizeof(int32_t), 256);
-    L.zero_bytes = off - L.zero_off;
     L.total = off;
     return L;
 }
@@ -985,8 +987,6 @@ extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scor
     float2 *kept_b = reinterpret_cast<float2 *>(ws + L.kept_b);
     int32_t *kcount = reinterpret_cast<int32_t *>(ws + L.kcount);
     int32_t *koff = reinterpret_cast<int32_t *>(ws + L.koff);
-    int32_t *err = reinterpret_cast<int32_t *>(ws + L.err);
-    DETBOX_HIP(hipMemsetAsync(ws + L.zero_off, 0, L.zero_bytes, st));
 
     NmsParams np;
     np.S = (int)S; np.max_seg = (int)max_segment; np.presorted = presorted ? 1 : 0;
@@ -1015,7 +1015,7 @@ extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scor
         if (lds > 64 * 1024)                                                                                     \
             DETBOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_segments_fast_kernel<J, BLKC>),    \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
-        nms_segments_fast_kernel<J, BLKC><<<grid, dim3(BLKC), lds, st>>>(b4, scores, seg_offsets, np, kept_a, kcount, err); \
+        nms_segments_fast_kernel<J, BLKC><<<grid, dim3(BLKC), lds, st>>>(b4, scores, seg_offsets, np, kept_a, kcount); \
     }
             const int jpt = (int)((max_segment + blk - 1) / blk);
             if (blk == 64) {
@@ -1033,13 +1033,13 @@ extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scor
             if (lds > 64 * 1024)
                 DETBOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_segments_generic_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            nms_segments_generic_kernel<<<grid, dim3(NMS_BLOCK), lds, st>>>(b4, scores, seg_offsets, np, kept_a, kcount, err);
+            nms_segments_generic_kernel<<<grid, dim3(NMS_BLOCK), lds, st>>>(b4, scores, seg_offsets, np, kept_a, kcount);
         }
         DETBOX_LAUNCH_CHECK();
     }
     {
         ProfScope ps("nms_scan", st);
-        nms_scan_kernel<<<dim3((unsigned)B), dim3(64), 0, st>>>(kcount, (int)S, koff, err, keep_counts);
+        nms_scan_kernel<<<dim3((unsigned)B), dim3(64), 0, st>>>(kcount, (int)S, koff, keep_counts);
         DETBOX_LAUNCH_CHECK();
     }
     float2 *src = kept_a, *dst = kept_b;

@@ -428,18 +428,27 @@ __device__ inline void find_kth_bin(uint4 q, uint32_t suf, uint32_t t, int lane,
 // Per (image, class): the sample_m-th largest sampled score, found exactly by a 4-round radix search
 // on the monotone uint32 image of the scores; it becomes the staging threshold t_lo of the scan.
 // With no more than sample_m sampled scores above the threshold, everything above it is staged.
+static_assert(NB == 256, "select_plan_kernel clears one histogram row with one store per thread");
 __global__ __launch_bounds__(256) void select_plan_kernel(const float *__restrict__ samp, SelParams sp,
-                                                          SelRule *__restrict__ rules, uint32_t *__restrict__ flag) {
+                                                          SelRule *__restrict__ rules, uint32_t *__restrict__ flag,
+                                                          uint32_t *__restrict__ gcnt, uint32_t *__restrict__ img_ovf,
+                                                          uint32_t *__restrict__ ghist) {
     extern __shared__ uint32_t s_key[];              // [ns_cap] keys of the sampled scores above the threshold (0 = none)
     __shared__ uint32_t s_h[256];
     __shared__ uint32_t s_pref, s_rem, s_total, s_max;
     const int ci = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     SelRule r;
     r.pad = 0; r.cutoff = 0ull; r.n_above = 0; r.n_sel = 0;
+    // first kernel of a call: the counters and flags the later kernels add to start from zero
+    if (tid == 0) {
+        gcnt[(size_t)b * sp.Cs + ci] = 0u;
+        if (ci == 0) img_ovf[b] = 0u;
+        if (ci == 0 && b == 0) *flag = sp.use_sample ? 0u : 1u;
+    }
     if (!sp.use_sample) {
-        if (b == 0 && ci == 0 && tid == 0) *flag = 1u;
         r.mode = RULE_PENDING; r.beta = 0; r.min_score = __builtin_inff();
         if (tid == 0) rules[(size_t)b * sp.Cs + ci] = r;
+        ghist[((size_t)b * sp.Cs + ci) * NB + tid] = 0u;        // NB == 256 == blockDim.x
         return;
     }
     if (tid == 0) { s_total = 0u; s_pref = 0u; s_rem = (uint32_t)sp.sample_m; s_max = 0u; }
@@ -627,20 +636,33 @@ __global__ __launch_bounds__(256) void select_bucket_kernel(SelParams sp, const 
 
 __global__ __launch_bounds__(128) void select_check_kernel(SelParams sp, SelRule *__restrict__ rules,
                                                            uint32_t *__restrict__ gcnt, const uint32_t *__restrict__ img_ovf,
-                                                           uint32_t *__restrict__ flag) {
+                                                           uint32_t *__restrict__ flag, uint32_t *__restrict__ ghist) {
+    __shared__ uint32_t s_pending[MAX_SEL_CLASSES];
     const int b = blockIdx.x, ci = threadIdx.x;
-    if (ci >= sp.Cs) return;
-    SelRule *r = rules + (size_t)b * sp.Cs + ci;
-    if (r->mode != RULE_STAGED) return;
-    const uint32_t n = gcnt[(size_t)b * sp.Cs + ci];
-    const bool ok = !img_ovf[b] && n <= (uint32_t)sp.cap && (r->beta != 0u || n >= (uint32_t)sp.top_k);
-    if (ok) {
-        r->n_sel = n < (uint32_t)sp.top_k ? n : (uint32_t)sp.top_k;
-    } else {
-        r->mode = RULE_PENDING;
-        gcnt[(size_t)b * sp.Cs + ci] = 0u;
-        atomicOr(flag, 1u);
+    bool pending = false;
+    if (ci < sp.Cs) {
+        SelRule *r = rules + (size_t)b * sp.Cs + ci;
+        if (r->mode == RULE_STAGED) {
+            const uint32_t n = gcnt[(size_t)b * sp.Cs + ci];
+            const bool ok = !img_ovf[b] && n <= (uint32_t)sp.cap && (r->beta != 0u || n >= (uint32_t)sp.top_k);
+            if (ok) {
+                r->n_sel = n < (uint32_t)sp.top_k ? n : (uint32_t)sp.top_k;
+            } else {
+                r->mode = RULE_PENDING;
+                gcnt[(size_t)b * sp.Cs + ci] = 0u;
+                atomicOr(flag, 1u);
+                pending = true;
+            }
+        }
     }
+    s_pending[threadIdx.x] = pending ? 1u : 0u;
+    if (!__syncthreads_or(pending ? 1 : 0)) return;
+    // a segment handed to the exact path starts from an empty histogram
+    for (int c = 0; c < sp.Cs; ++c)
+        if (s_pending[c]) {
+            uint32_t *h = ghist + ((size_t)b * sp.Cs + c) * NB;
+            for (int i = threadIdx.x; i < NB; i += 128) h[i] = 0u;
+        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1155,7 +1177,7 @@ SelPlan make_plan(int64_t B, int64_t P, int64_t C, int64_t Cs, int top_k) {
     return sp;
 }
 
-struct SelLayout { size_t hist, cnt, flag, img_ovf, blk_cnt, rules, staging, samp, blk_list, scores, total, zero_bytes; };
+struct SelLayout { size_t hist, cnt, flag, img_ovf, blk_cnt, rules, staging, samp, blk_list, scores, total; };
 
 SelLayout layout(int64_t B, int64_t P, int64_t C, int64_t Cs, const SelPlan &pl, int act) {
     SelLayout L;
@@ -1165,7 +1187,6 @@ SelLayout layout(int64_t B, int64_t P, int64_t C, int64_t Cs, const SelPlan &pl,
     L.flag = off; off = align_up(off + sizeof(uint32_t), 256);
     L.img_ovf = off; off = align_up(off + (size_t)B * sizeof(uint32_t), 256);
     L.blk_cnt = off; off = align_up(off + (size_t)B * pl.scan_gx * 4 * sizeof(uint32_t), 256);
-    L.zero_bytes = off;                      // histogram, counters and flags are cleared every call
     L.rules = off; off = align_up(off + (size_t)B * Cs * sizeof(SelRule), 256);
     L.staging = off; off = align_up(off + (size_t)B * Cs * pl.cap * sizeof(unsigned long long), 256);
     L.samp = off; off = align_up(off + (size_t)B * Cs * pl.ns_cap * sizeof(float), 256);
@@ -1187,7 +1208,7 @@ struct FastArgs {
     const float *in, *extra;
     SelParams sp;
     int64_t B;
-    uint32_t *flag, *cnt, *img_ovf, *blk_cnt;
+    uint32_t *flag, *cnt, *img_ovf, *blk_cnt, *hist;
     SelRule *rules;
     unsigned long long *staging, *blk_list;
     float *samp, *scores_ws;
@@ -1212,7 +1233,7 @@ struct LaunchFast {
             const size_t lds = (size_t)sp.ns_cap * 4;
             if (int rc = set_lds(select_plan_kernel, lds)) return rc;
             ProfScope ps("select_plan", s);
-            select_plan_kernel<<<dim3((unsigned)sp.Cs, (unsigned)a.B), dim3(256), lds, s>>>(a.samp, sp, a.rules, a.flag);
+            select_plan_kernel<<<dim3((unsigned)sp.Cs, (unsigned)a.B), dim3(256), lds, s>>>(a.samp, sp, a.rules, a.flag, a.cnt, a.img_ovf, a.hist);
             DETBOX_LAUNCH_CHECK();
         }
         const unsigned gx = (unsigned)sp.scan_gx;
@@ -1231,7 +1252,7 @@ struct LaunchFast {
                 DETBOX_LAUNCH_CHECK();
             }
             ProfScope ps("select_check", s);
-            select_check_kernel<<<dim3((unsigned)a.B), dim3(128), 0, s>>>(sp, a.rules, a.cnt, a.img_ovf, a.flag);
+            select_check_kernel<<<dim3((unsigned)a.B), dim3(128), 0, s>>>(sp, a.rules, a.cnt, a.img_ovf, a.flag, a.hist);
             DETBOX_LAUNCH_CHECK();
         }
         if (ACT != ACT_NONE) {
@@ -1405,10 +1426,9 @@ extern "C" int detbox_select_decode(int decode_mode, int activation, const float
     sp.tile_floats = tile_floats_for(C);
     sp.total_floats = (long long)B * P * C;
 
-    DETBOX_HIP(hipMemsetAsync(ws, 0, L.zero_bytes, s));
     {
         FastArgs a;
-        a.in = scores; a.extra = extra; a.sp = sp; a.B = B; a.flag = flag; a.cnt = cnt; a.img_ovf = img_ovf;
+        a.in = scores; a.extra = extra; a.sp = sp; a.B = B; a.flag = flag; a.cnt = cnt; a.img_ovf = img_ovf; a.hist = ghist;
         a.blk_cnt = blk_cnt; a.rules = rules; a.staging = staging; a.blk_list = blk_list; a.samp = samp;
         a.scores_ws = scores_ws; a.s = s;
         if (int rc = dispatch_act_ept<LaunchFast>(activation, ept_for(C), a)) return rc;

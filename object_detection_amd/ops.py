@@ -14,6 +14,8 @@ the host, and a missing library or GPU raises.
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -41,6 +43,10 @@ def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+# DETBOX_POISON_WORKSPACE=1 (tests): every call finds its workspace filled with garbage
+_POISON = bool(os.environ.get('DETBOX_POISON_WORKSPACE'))
+
+
 def _workspace(device, nbytes: int, tag: str) -> torch.Tensor:
     """Grow-only scratch buffer per (device, operator, stream): calls that share one are ordered on that stream."""
     key = (device.index, tag, _stream(device))
@@ -48,6 +54,8 @@ def _workspace(device, nbytes: int, tag: str) -> torch.Tensor:
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
+    if _POISON:
+        ws.fill_(0xA5)       # the operators must not rely on what a workspace holds on entry
     return ws
 
 

@@ -823,3 +823,30 @@ def test_ops_accept_views_and_other_dtypes(D, oracle, dev):
     keep_a, kc_a = D.ops.nms_candidates(ref, 0.45)
     keep_b, kc_b = D.ops.nms_segments(ref.boxes.double(), ref.scores.double(), ref.seg_offsets.long(), 0.45, max_segment=50)
     assert torch.equal(kc_a, kc_b) and torch.equal(keep_a[1, :int(kc_a[1])], keep_b[1, :int(kc_b[1])])
+
+
+def test_operators_do_not_depend_on_workspace_contents(D, oracle, dev):
+    """Workspaces are caller-owned and arrive with arbitrary contents: the same calls with the workspace
+    filled with garbage first (ops._POISON) give the same results, on the sampled and on the exact path."""
+    g = torch.Generator().manual_seed(11)
+    results = []
+    for poison in (False, True):
+        D.ops._POISON = poison
+        try:
+            out = []
+            for P, k in ((9000, 100), (700, 40)):              # sampled fast path / exact path for small P
+                scores = torch.rand(4, P, 6, generator=torch.Generator().manual_seed(P)).to(dev)
+                locs = torch.randn(4, P, 4, generator=torch.Generator().manual_seed(P + 1)).to(dev)
+                anchors = (torch.rand(P, 4, generator=torch.Generator().manual_seed(P + 2)) * 0.5 + 0.2).to(dev)
+                c = D.ops.select_decode(scores, locs, anchors, D.ops.DECODE_CXCYWH, 1, 0, 0.2, k)
+                keep, kc = D.ops.nms_candidates(c, 0.45)
+                out += [c.counts.clone(), c.seg_offsets.clone(), kc.clone(), keep[0, :int(kc[0])].clone(),
+                        c.scores[1, :int(c.counts[1])].clone()]
+            m = D.SSD300(20)
+            gts = [oracle.synth_gt(i, 20, False) for i in range(3)]
+            out += list(m.assign([q[0] for q in gts], [q[1] for q in gts], dev))
+            results.append(out)
+        finally:
+            D.ops._POISON = False
+    assert all(torch.equal(a, b) for a, b in zip(*results))
+    assert int(results[0][2].min()) >= 0
