@@ -567,10 +567,8 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == 256 
                     if (act[m]) m_first = m;
                 auto sweep = [&](auto first_slot) {
                     constexpr int M0 = decltype(first_slot)::value;
-                    uint4 kq_next = s_kq[0];                     // broadcast LDS reads, one kept box ahead
-                    for (int t = 0; t < nk; ++t) {
-                        const uint32_t klo = kq_next.x, khi = kq_next.y, ktb = kq_next.z;
-                        kq_next = s_kq[t + 1];
+                    auto against = [&](const int t, const uint4 kq) {
+                        const uint32_t klo = kq.x, khi = kq.y, ktb = kq.z;
                         // stage 1 for every live slot first (independent chains, one branch for all of them):
                         // integer upper bound of the intersection against the threshold shares
                         unsigned long long open_m[JPT];
@@ -583,7 +581,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == 256 
                             open_m[m] = act[m] & ~__ballot(inter_up_biased(d, qTn[m]) <= ktb);
                             any_open |= open_m[m];
                         }
-                        if (!any_open) continue;
+                        if (!any_open) return;
 #pragma unroll
                         for (int m = M0; m < JPT; ++m) {
                             const unsigned long long open = open_m[m];
@@ -609,6 +607,15 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == 256 
                                 hit[m] |= yes;
                             }
                         }
+                    };
+                    // broadcast LDS reads one kept box ahead; two per trip so that the prefetched box needs no register copy
+                    uint4 k0 = s_kq[0];
+                    for (int t = 0; t < nk; t += 2) {
+                        const uint4 k1 = s_kq[t + 1];
+                        against(t, k0);
+                        if (t + 1 >= nk) break;
+                        k0 = s_kq[t + 2];
+                        against(t + 1, k1);
                     }
                 };
                 switch (m_first / GS) {
