@@ -53,6 +53,8 @@ __global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
     __shared__ float s_area[GCHUNK];
     __shared__ float2 s_xy[GCHUNK];                 // YOLO: raw GT top-left
     __shared__ unsigned long long s_col[GCHUNK];
+    __shared__ float4 s_raw[GCHUNK];                // the GT boxes as given, for the encoding
+    __shared__ int64_t s_lbl[GCHUNK];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -78,6 +80,11 @@ __global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
         gx_hi = a0 + grid; gy_hi = a1 + grid;
     }
     const float area_a = (ax2 - ax1) * (ay2 - ay1);
+    // Bounds of the 64 anchors of this wave: a GT box that lies outside them has IoU exactly 0 with every lane,
+    // so the wave steps over it (an IoU of 0 never enters the per-GT arg-max).
+    const float inf = __builtin_inff();
+    const float wx1 = -wave_max(valid ? -ax1 : -inf), wy1 = -wave_max(valid ? -ay1 : -inf);
+    const float wx2 = wave_max(valid ? ax2 : -inf), wy2 = wave_max(valid ? ay2 : -inf);
 
     const int b_begin = blockIdx.y * imgs_per_block;
     const int b_end = min(B, b_begin + imgs_per_block);
@@ -105,10 +112,17 @@ __global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
                 s_area[tid] = (x.z - x.x) * (x.w - x.y);
                 s_xy[tid] = make_float2(g.x, g.y);
                 s_col[tid] = 0ull;
+                s_raw[tid] = g;
+                s_lbl[tid] = gt_labels[g0 + c0 + tid];
             }
             __syncthreads();
             for (int j = 0; j < gc; ++j) {
                 const float4 g = s_xyxy[j];
+                // the same value in every lane: the width or the height of every intersection clamps to 0
+                if (__ballot(g.x >= wx2 || g.z <= wx1 || g.y >= wy2 || g.w <= wy1) != 0ull) {
+                    if (0.0f > best) { best = 0.0f; bidx = c0 + j; }       // what an IoU of 0 does below
+                    continue;
+                }
                 const float w = fmaxf(fminf(ax2, g.z) - fmaxf(ax1, g.x), 0.0f);
                 const float h = fmaxf(fminf(ay2, g.w) - fmaxf(ay1, g.y), 0.0f);
                 const float inter = w * h;
@@ -140,8 +154,11 @@ __global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
             }
         }
         if (valid) {
-            const float4 g = gt_boxes[g0 + bidx];
-            const int64_t lbl = gt_labels[g0 + bidx];
+            // the last chunk is still in LDS (the only one unless an image has more than GCHUNK boxes)
+            const int c_last = ((G - 1) / GCHUNK) * GCHUNK;
+            const bool in_lds = bidx >= c_last;
+            const float4 g = in_lds ? s_raw[bidx - c_last] : gt_boxes[g0 + bidx];
+            const int64_t lbl = in_lds ? s_lbl[bidx - c_last] : gt_labels[g0 + bidx];
             float4 d;
             if (MODE == DETBOX_ASSIGN_CXCYWH) {
                 d.x = (10.0f * (g.x - a0)) / a2;
