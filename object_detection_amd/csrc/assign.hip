@@ -18,6 +18,7 @@
 // torch.min on CPU: rows by a strict compare in ascending GT order, columns by
 // packing (iou bits, ~anchor index) into one 64-bit key.
 #include "detbox_internal.h"
+#include <cstdlib>
 
 using namespace detbox;
 
@@ -42,7 +43,9 @@ __device__ inline float wave_max(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-template <int MODE>
+// APT anchors per thread (anchor m of a thread is 256 anchors after anchor m-1): with several, the staging of
+// an image's GT boxes, the barriers and the per-GT atomics are shared by APT * 256 anchors.
+template <int MODE, int APT>
 __global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
     const float *__restrict__ anchors, int P,
     const float4 *__restrict__ gt_boxes, const int64_t *__restrict__ gt_labels,
@@ -57,47 +60,66 @@ __global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
     __shared__ int64_t s_lbl[GCHUNK];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int p = blockIdx.x * ASSIGN_BLOCK + tid;
-    const bool valid = p < P;
+    const int p0 = blockIdx.x * (ASSIGN_BLOCK * APT) + tid;
 
-    // anchor in registers: raw (for encoding), xyxy + area (for IoU)
-    float a0 = 0.f, a1 = 0.f, a2 = 1.f, a3 = 1.f, grid = 1.f;
-    if (valid) {
+    // anchors in registers: raw (for encoding), xyxy + area (for IoU)
+    float a0[APT], a1[APT], a2[APT], a3[APT], grid[APT];
+    float ax1[APT], ay1[APT], ax2[APT], ay2[APT], gx_hi[APT], gy_hi[APT], area_a[APT];
+    bool valid[APT];
+    const float inf = __builtin_inff();
+    float bx1 = inf, by1 = inf, bx2 = -inf, by2 = -inf;
+#pragma unroll
+    for (int m = 0; m < APT; ++m) {
+        const int p = p0 + m * ASSIGN_BLOCK;
+        valid[m] = p < P;
+        a0[m] = 0.f; a1[m] = 0.f; a2[m] = 1.f; a3[m] = 1.f; grid[m] = 1.f;
+        if (valid[m]) {
+            if (MODE == DETBOX_ASSIGN_CXCYWH) {
+                const float4 a = reinterpret_cast<const float4 *>(anchors)[p];
+                a0[m] = a.x; a1[m] = a.y; a2[m] = a.z; a3[m] = a.w;
+            } else {
+                const float *a = anchors + (size_t)p * 5;
+                a0[m] = a[0]; a1[m] = a[1]; a2[m] = a[2]; a3[m] = a[3]; grid[m] = a[4];
+            }
+        }
+        gx_hi[m] = 0.f; gy_hi[m] = 0.f;
         if (MODE == DETBOX_ASSIGN_CXCYWH) {
-            float4 a = reinterpret_cast<const float4 *>(anchors)[p];
-            a0 = a.x; a1 = a.y; a2 = a.z; a3 = a.w;
+            ax1[m] = a0[m] - 0.5f * a2[m]; ay1[m] = a1[m] - 0.5f * a3[m];
+            ax2[m] = a0[m] + 0.5f * a2[m]; ay2[m] = a1[m] + 0.5f * a3[m];
         } else {
-            const float *a = anchors + (size_t)p * 5;
-            a0 = a[0]; a1 = a[1]; a2 = a[2]; a3 = a[3]; grid = a[4];
+            ax1[m] = a0[m]; ay1[m] = a1[m]; ax2[m] = a0[m] + a2[m]; ay2[m] = a1[m] + a3[m];
+            gx_hi[m] = a0[m] + grid[m]; gy_hi[m] = a1[m] + grid[m];
+        }
+        area_a[m] = (ax2[m] - ax1[m]) * (ay2[m] - ay1[m]);
+        if (valid[m]) {
+            bx1 = fminf(bx1, ax1[m]); by1 = fminf(by1, ay1[m]);
+            bx2 = fmaxf(bx2, ax2[m]); by2 = fmaxf(by2, ay2[m]);
         }
     }
-    float ax1, ay1, ax2, ay2, gx_hi = 0.f, gy_hi = 0.f;
-    if (MODE == DETBOX_ASSIGN_CXCYWH) {
-        ax1 = a0 - 0.5f * a2; ay1 = a1 - 0.5f * a3; ax2 = a0 + 0.5f * a2; ay2 = a1 + 0.5f * a3;
-    } else {
-        ax1 = a0; ay1 = a1; ax2 = a0 + a2; ay2 = a1 + a3;
-        gx_hi = a0 + grid; gy_hi = a1 + grid;
-    }
-    const float area_a = (ax2 - ax1) * (ay2 - ay1);
-    // Bounds of the 64 anchors of this wave: a GT box that lies outside them has IoU exactly 0 with every lane,
-    // so the wave steps over it (an IoU of 0 never enters the per-GT arg-max).
-    const float inf = __builtin_inff();
-    const float wx1 = -wave_max(valid ? -ax1 : -inf), wy1 = -wave_max(valid ? -ay1 : -inf);
-    const float wx2 = wave_max(valid ? ax2 : -inf), wy2 = wave_max(valid ? ay2 : -inf);
+    // Bounds of the anchors of this wave: a GT box that lies outside them has IoU exactly 0 with every one of
+    // them, so the wave steps over it (an IoU of 0 never enters the per-GT arg-max).
+    const float wx1 = -wave_max(-bx1), wy1 = -wave_max(-by1);
+    const float wx2 = wave_max(bx2), wy2 = wave_max(by2);
 
     const int b_begin = blockIdx.y * imgs_per_block;
     const int b_end = min(B, b_begin + imgs_per_block);
     for (int b = b_begin; b < b_end; ++b) {
         const int g0 = gt_off[b];
         const int G = gt_off[b + 1] - g0;
-        const size_t o = (size_t)b * P + p;
+        const size_t o0 = (size_t)b * P + p0;
         if (G <= 0) {
-            if (valid) { locs[o] = make_float4(0.f, 0.f, 0.f, 0.f); labels[o] = 0; matched[o] = -1; }
+#pragma unroll
+            for (int m = 0; m < APT; ++m)
+                if (valid[m]) {
+                    const size_t o = o0 + m * ASSIGN_BLOCK;
+                    locs[o] = make_float4(0.f, 0.f, 0.f, 0.f); labels[o] = 0; matched[o] = -1;
+                }
             continue;
         }
-        float best = -1.0f;
-        int bidx = 0;
+        float best[APT];
+        int bidx[APT];
+#pragma unroll
+        for (int m = 0; m < APT; ++m) { best[m] = -1.0f; bidx[m] = 0; }
         for (int c0 = 0; c0 < G; c0 += GCHUNK) {
             const int gc = min(GCHUNK, G - c0);
             __syncthreads();
@@ -120,30 +142,37 @@ __global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
                 const float4 g = s_xyxy[j];
                 // the same value in every lane: the width or the height of every intersection clamps to 0
                 if (__ballot(g.x >= wx2 || g.z <= wx1 || g.y >= wy2 || g.w <= wy1) != 0ull) {
-                    if (0.0f > best) { best = 0.0f; bidx = c0 + j; }       // what an IoU of 0 does below
+#pragma unroll
+                    for (int m = 0; m < APT; ++m)
+                        if (0.0f > best[m]) { best[m] = 0.0f; bidx[m] = c0 + j; }       // what an IoU of 0 does below
                     continue;
                 }
-                const float w = fmaxf(fminf(ax2, g.z) - fmaxf(ax1, g.x), 0.0f);
-                const float h = fmaxf(fminf(ay2, g.w) - fmaxf(ay1, g.y), 0.0f);
-                const float inter = w * h;
-                float iou = 0.0f;
-                // inter == 0 gives exactly +0 (the union is positive), so the division is skipped
-                if (inter > 0.0f) iou = inter / ((area_a + s_area[j]) - inter);
-                if (!valid) iou = 0.0f;
-                if (iou > best) { best = iou; bidx = c0 + j; }
-                float v = iou;
-                if (MODE == DETBOX_ASSIGN_YOLO) {
-                    const float2 q = s_xy[j];
-                    const bool in_grid = (a0 <= q.x) && (q.x < gx_hi) && (a1 <= q.y) && (q.y < gy_hi);
-                    v = in_grid ? iou : 0.0f;
+                const float ga = s_area[j];
+                float vmax = 0.0f;                      // largest IoU of this thread's anchors with GT j, first anchor on ties
+                int mmax = 0;
+#pragma unroll
+                for (int m = 0; m < APT; ++m) {
+                    const float w = fmaxf(fminf(ax2[m], g.z) - fmaxf(ax1[m], g.x), 0.0f);
+                    const float h = fmaxf(fminf(ay2[m], g.w) - fmaxf(ay1[m], g.y), 0.0f);
+                    const float inter = w * h;
+                    float iou = 0.0f;
+                    // inter == 0 gives exactly +0 (the union is positive), so the division is skipped
+                    if (inter > 0.0f) iou = inter / ((area_a[m] + ga) - inter);
+                    if (!valid[m]) iou = 0.0f;
+                    if (iou > best[m]) { best[m] = iou; bidx[m] = c0 + j; }
+                    float v = iou;
+                    if (MODE == DETBOX_ASSIGN_YOLO) {
+                        const float2 q = s_xy[j];
+                        const bool in_grid = (a0[m] <= q.x) && (q.x < gx_hi[m]) && (a1[m] <= q.y) && (q.y < gy_hi[m]);
+                        v = in_grid ? iou : 0.0f;
+                    }
+                    if (v > vmax) { vmax = v; mmax = m; }
                 }
-                if (__ballot(v > 0.0f) != 0ull) {           // wave-uniform
-                    const float m = wave_max(v);
-                    const unsigned long long eq = __ballot(v == m);
-                    if (lane == __ffsll((long long)eq) - 1) {
-                        const unsigned long long key =
-                            ((unsigned long long)__float_as_uint(m) << 32) | (unsigned long long)(0xffffffffu - (unsigned)p);
-                        atomicMax(&s_col[j], key);
+                if (__ballot(vmax > 0.0f) != 0ull) {           // wave-uniform
+                    const float wm = wave_max(vmax);
+                    if (vmax == wm) {                          // several lanes only on exact ties: the lowest anchor wins the max
+                        const unsigned p = (unsigned)(p0 + mmax * ASSIGN_BLOCK);
+                        atomicMax(&s_col[j], ((unsigned long long)__float_as_uint(wm) << 32) | (unsigned long long)(0xffffffffu - p));
                     }
                 }
             }
@@ -153,25 +182,28 @@ __global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
                 if (k != 0ull) atomicMax(&colbest[g0 + c0 + tid], k);
             }
         }
-        if (valid) {
-            // the last chunk is still in LDS (the only one unless an image has more than GCHUNK boxes)
-            const int c_last = ((G - 1) / GCHUNK) * GCHUNK;
-            const bool in_lds = bidx >= c_last;
-            const float4 g = in_lds ? s_raw[bidx - c_last] : gt_boxes[g0 + bidx];
-            const int64_t lbl = in_lds ? s_lbl[bidx - c_last] : gt_labels[g0 + bidx];
+        // the last chunk is still in LDS (the only one unless an image has more than GCHUNK boxes)
+        const int c_last = ((G - 1) / GCHUNK) * GCHUNK;
+#pragma unroll
+        for (int m = 0; m < APT; ++m) {
+            if (!valid[m]) continue;
+            const size_t o = o0 + m * ASSIGN_BLOCK;
+            const bool in_lds = bidx[m] >= c_last;
+            const float4 g = in_lds ? s_raw[bidx[m] - c_last] : gt_boxes[g0 + bidx[m]];
+            const int64_t lbl = in_lds ? s_lbl[bidx[m] - c_last] : gt_labels[g0 + bidx[m]];
             float4 d;
             if (MODE == DETBOX_ASSIGN_CXCYWH) {
-                d.x = (10.0f * (g.x - a0)) / a2;
-                d.y = (10.0f * (g.y - a1)) / a3;
+                d.x = (10.0f * (g.x - a0[m])) / a2[m];
+                d.y = (10.0f * (g.y - a1[m])) / a3[m];
             } else {
-                d.x = (10.0f * (g.x - a0)) / grid;
-                d.y = (10.0f * (g.y - a1)) / grid;
+                d.x = (10.0f * (g.x - a0[m])) / grid[m];
+                d.y = (10.0f * (g.y - a1[m])) / grid[m];
             }
-            d.z = 5.0f * logf(g.z / a2);
-            d.w = 5.0f * logf(g.w / a3);
+            d.z = 5.0f * logf(g.z / a2[m]);
+            d.w = 5.0f * logf(g.w / a3[m]);
             locs[o] = d;
-            matched[o] = bidx;
-            labels[o] = (best < thr_lo) ? 0 : ((best < thr_hi) ? -1 : lbl);
+            matched[o] = bidx[m];
+            labels[o] = (best[m] < thr_lo) ? 0 : ((best[m] < thr_hi) ? -1 : lbl);
         }
     }
 }
@@ -298,19 +330,20 @@ extern "C" int detbox_assign_anchor(int mode, const float *anchors, int64_t P,
     hipStream_t s = static_cast<hipStream_t>(stream);
     unsigned long long *colbest = static_cast<unsigned long long *>(workspace);
     if (total_gt > 0) DETBOX_HIP(hipMemsetAsync(colbest, 0, (size_t)total_gt * sizeof(unsigned long long), s));
-    const int64_t tiles = (P + ASSIGN_BLOCK - 1) / ASSIGN_BLOCK;
+    // four anchors per thread once that still leaves about four workgroups per CU (33 against 44 us on 16 x 120087 anchors)
+    const int apt = (P * B >= (int64_t)4 * ASSIGN_BLOCK * 1024) ? 4 : 1;
+    const int64_t tiles = (P + ASSIGN_BLOCK * apt - 1) / (ASSIGN_BLOCK * apt);
     const int ipb = pick_imgs_per_block(tiles, B);
     dim3 grid((unsigned)tiles, (unsigned)((B + ipb - 1) / ipb));
     {
         ProfScope ps("assign_anchor", s);
-        if (mode == DETBOX_ASSIGN_CXCYWH)
-            assign_anchor_kernel<DETBOX_ASSIGN_CXCYWH><<<grid, dim3(ASSIGN_BLOCK), 0, s>>>(
-                anchors, (int)P, reinterpret_cast<const float4 *>(gt_boxes), gt_labels, gt_offsets, (int)B, ipb,
-                thr_lo, thr_hi, reinterpret_cast<float4 *>(target_locs), target_labels, matched, colbest);
-        else
-            assign_anchor_kernel<DETBOX_ASSIGN_YOLO><<<grid, dim3(ASSIGN_BLOCK), 0, s>>>(
-                anchors, (int)P, reinterpret_cast<const float4 *>(gt_boxes), gt_labels, gt_offsets, (int)B, ipb,
-                thr_lo, thr_hi, reinterpret_cast<float4 *>(target_locs), target_labels, matched, colbest);
+#define DETBOX_ASSIGN(MODE, APT)                                                                                   \
+    assign_anchor_kernel<MODE, APT><<<grid, dim3(ASSIGN_BLOCK), 0, s>>>(                                           \
+        anchors, (int)P, reinterpret_cast<const float4 *>(gt_boxes), gt_labels, gt_offsets, (int)B, ipb, thr_lo,   \
+        thr_hi, reinterpret_cast<float4 *>(target_locs), target_labels, matched, colbest)
+        if (mode == DETBOX_ASSIGN_CXCYWH) { if (apt == 4) DETBOX_ASSIGN(DETBOX_ASSIGN_CXCYWH, 4); else DETBOX_ASSIGN(DETBOX_ASSIGN_CXCYWH, 1); }
+        else { if (apt == 4) DETBOX_ASSIGN(DETBOX_ASSIGN_YOLO, 4); else DETBOX_ASSIGN(DETBOX_ASSIGN_YOLO, 1); }
+#undef DETBOX_ASSIGN
         DETBOX_LAUNCH_CHECK();
     }
     if (total_gt > 0) {

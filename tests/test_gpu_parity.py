@@ -718,6 +718,12 @@ def test_retinanet800_full_size(D, oracle, dev):
     gb, gl = [g_[0] for g_ in gts], [g_[1] for g_ in gts]
     got = m.assign(gb, gl, dev, want_best=True)
     check_assign(got, O.assign_retinanet(m.pboxes, gb, gl), 'retina')
+    # a batch large enough for the four-anchors-per-thread form of the kernel (P * B >= 2^20)
+    gts = [O.synth_gt(i, 80, True) for i in range(40, 50)]
+    gb, gl = [g_[0] for g_ in gts], [g_[1] for g_ in gts]
+    assert P * len(gts) >= 1 << 20
+    got = m.assign(gb, gl, dev, want_best=True)
+    check_assign(got, O.assign_retinanet(m.pboxes, gb, gl), 'retina')
 
 
 def test_bench_workload_properties_full_batch(D, oracle, dev):
