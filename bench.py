@@ -191,6 +191,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle timing (profiling runs)')
     ap.add_argument('--graph', action='store_true',
                     help='N=1 only: capture one step in a HIP graph and replay it in the timed region (launch-bound workloads)')
+    ap.add_argument('--streams', type=int, default=2,
+                    help='steps are issued round-robin on this many HIP streams (independent batches in flight)')
     ap.add_argument('--exchange', default='root', choices=['root', 'all'],
                     help='N>1: detections are gathered to rank 0 (one evaluator process) or to every rank')
     args = ap.parse_args()
@@ -274,11 +276,22 @@ def main():
             graph_out = wl.step(world)
         graph.replay()
         torch.cuda.synchronize()
+    streams = None
+    if args.streams > 1 and graph is None:
+        streams = [torch.cuda.Stream(dev) for _ in range(args.streams)]
+        for st in streams:                            # workspaces and allocator pools of every stream exist before the clock starts
+            st.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(st):
+                wl.step(world)
+        torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         if graph is not None:
             graph.replay()
+        elif streams is not None:
+            with torch.cuda.stream(streams[i % len(streams)]):
+                wl.step(world)
         else:
             wl.step(world)
     barrier()
@@ -332,10 +345,10 @@ def main():
             'metric': 'images/sec assign+decode+NMS', 'value': ips, 'unit': 'images/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'launch': 'hip-graph replay' if graph is not None else 'stream',
+            'launch': 'hip-graph replay' if graph is not None else ('stream' if streams is None else f'{len(streams)} streams, steps round-robin'),
             'config': {'workload': f'{args.workload} {args.regime}: B={B}/GPU P={P} C={C} top_k={wl.top_k} conf>0.01 nms=0.45',
                        'images_per_gpu': B, 'global_batch': world * B, 'candidates_per_image': n_cand,
-                       'kept_per_image': n_keep, 'gt_per_image': G_mean, 'parallelism': f'image-sharded x{world}', 'exchange': ('none' if world == 1 else ('gather to rank 0' if args.exchange == 'root' else 'all-gather'))},
+                       'kept_per_image': n_keep, 'gt_per_image': G_mean, 'parallelism': f'image-sharded x{world}', 'streams': (1 if streams is None else len(streams)), 'exchange': ('none' if world == 1 else ('gather to rank 0' if args.exchange == 'root' else 'all-gather'))},
             'roofline': roofline,
             'roofline_streaming': streaming,
             'cpu_baseline': cpu,
