@@ -428,12 +428,15 @@ __device__ inline void find_kth_bin(uint4 q, uint32_t suf, uint32_t t, int lane,
 // Per (image, class): the sample_m-th largest sampled score, found exactly by a 4-round radix search
 // on the monotone uint32 image of the scores; it becomes the staging threshold t_lo of the scan.
 // With no more than sample_m sampled scores above the threshold, everything above it is staged.
-static_assert(NB == 256, "select_plan_kernel clears one histogram row with one store per thread");
-__global__ __launch_bounds__(256) void select_plan_kernel(const float *__restrict__ samp, SelParams sp,
+// BLK = 64: one wave per (image, class) -- its barriers cost nothing, which is what pays when there are many
+// short sample lists (thousands of segments); BLK = 256 shares a long list between four waves.
+static_assert(NB == 256, "the histogram of the radix round doubles as the 256-entry gather buffer");
+template <int BLK>
+__global__ __launch_bounds__(BLK) void select_plan_kernel(const float *__restrict__ samp, SelParams sp,
                                                           SelRule *__restrict__ rules, uint32_t *__restrict__ flag,
                                                           uint32_t *__restrict__ gcnt, uint32_t *__restrict__ img_ovf,
                                                           uint32_t *__restrict__ ghist) {
-    extern __shared__ uint32_t s_key[];              // [ns_cap] keys of the sampled scores above the threshold (0 = none)
+    extern __shared__ __align__(16) uint32_t s_key[];  // [ns_cap] keys of the sampled scores above the threshold (0 = none)
     __shared__ uint32_t s_h[256];
     __shared__ uint32_t s_pref, s_rem, s_total, s_max;
     const int ci = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
@@ -448,22 +451,28 @@ __global__ __launch_bounds__(256) void select_plan_kernel(const float *__restric
     if (!sp.use_sample) {
         r.mode = RULE_PENDING; r.beta = 0; r.min_score = __builtin_inff();
         if (tid == 0) rules[(size_t)b * sp.Cs + ci] = r;
-        ghist[((size_t)b * sp.Cs + ci) * NB + tid] = 0u;        // NB == 256 == blockDim.x
+        for (int i = tid; i < NB; i += BLK) ghist[((size_t)b * sp.Cs + ci) * NB + i] = 0u;
         return;
     }
     if (tid == 0) { s_total = 0u; s_pref = 0u; s_rem = (uint32_t)sp.sample_m; s_max = 0u; }
     __syncthreads();
     const float *sv = samp + ((size_t)b * sp.Cs + ci) * sp.ns_cap;
     uint32_t mine = 0, kmax = 0;
-    for (int i = tid; i < sp.ns_cap; i += 256) {
+    // 16-byte loads, two in flight per thread: the list is read once and the read is all latency
+    // (ns_cap is a multiple of SUB_ROWS, the list starts on a 256-byte boundary, rows beyond P hold no sample)
+#pragma unroll 2
+    for (int i = tid * 4; i < sp.ns_cap; i += BLK * 4) {
         const long long row = (long long)(i / SUB_ROWS) * sp.sample_rate * SUB_ROWS + (i % SUB_ROWS);
-        uint32_t k = 0u;
-        if (row < sp.P) {
-            const float v = sv[i];
-            if (v > sp.thr) { k = okey(v) - sp.key_thr; ++mine; }     // k >= 1
+        const float4 v4 = row < sp.P ? *reinterpret_cast<const float4 *>(sv + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        uint32_t k[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            k[q] = 0u;
+            if (row + q < sp.P && v[q] > sp.thr) { k[q] = okey(v[q]) - sp.key_thr; ++mine; }     // k >= 1
+            kmax = max(kmax, k[q]);
         }
-        s_key[i] = k;
-        kmax = max(kmax, k);
+        *reinterpret_cast<uint4 *>(s_key + i) = make_uint4(k[0], k[1], k[2], k[3]);
     }
     if (mine) { atomicAdd(&s_total, mine); atomicMax(&s_max, kmax); }
     __syncthreads();
@@ -476,9 +485,9 @@ __global__ __launch_bounds__(256) void select_plan_kernel(const float *__restric
             const int bits = width < 8 ? width : 8;
             const int shift = width - bits;
             const uint32_t pref = s_pref;
-            s_h[tid] = 0u;
+            for (int i = tid; i < 256; i += BLK) s_h[i] = 0u;
             __syncthreads();
-            for (int i = tid; i < sp.ns_cap; i += 256) {
+            for (int i = tid; i < sp.ns_cap; i += BLK) {
                 const uint32_t k = s_key[i];
                 if (k && (width == 32 || (k >> width) == (pref >> width))) atomicAdd(&s_h[(k >> shift) & ((1u << bits) - 1u)], 1u);
             }
@@ -499,24 +508,26 @@ __global__ __launch_bounds__(256) void select_plan_kernel(const float *__restric
                 // counting, instead of sweeping all the keys once more per remaining digit.
                 const uint32_t want = s_pref >> width, rem = s_rem;
                 uint32_t nf = 0;
-                for (int i = tid; i < sp.ns_cap; i += 256) {
+                for (int i = tid; i < sp.ns_cap; i += BLK) {
                     const uint32_t k = s_key[i];
                     nf += (k != 0u && (k >> width) == want);
                 }
                 uint32_t pos = nf ? atomicAdd(&s_max, nf) : 0u;
                 if (nf)
-                    for (int i = tid; i < sp.ns_cap; i += 256) {
+                    for (int i = tid; i < sp.ns_cap; i += BLK) {
                         const uint32_t k = s_key[i];
                         if (k != 0u && (k >> width) == want) s_h[pos++] = k;
                     }
                 __syncthreads();
-                const uint32_t mine_k = tid < (int)nd ? s_h[tid] : 0u;
-                uint32_t rk = 0;
-                for (uint32_t j = 0; j < nd; ++j) {
-                    const uint32_t v = s_h[j];
-                    rk += (v > mine_k || (v == mine_k && j < (uint32_t)tid));
+                for (uint32_t e = (uint32_t)tid; e < nd; e += BLK) {
+                    const uint32_t mine_k = s_h[e];
+                    uint32_t rk = 0;
+                    for (uint32_t j = 0; j < nd; ++j) {
+                        const uint32_t v = s_h[j];
+                        rk += (v > mine_k || (v == mine_k && j < e));
+                    }
+                    if (rk == rem - 1u) s_pref = mine_k;                    // rem <= nd: exactly one entry
                 }
-                if (tid < (int)nd && rk == rem - 1u) s_pref = mine_k;       // rem <= nd: exactly one thread
                 __syncthreads();
                 width = 0;
             }
@@ -1231,9 +1242,15 @@ struct LaunchFast {
         }
         {
             const size_t lds = (size_t)sp.ns_cap * 4;
-            if (int rc = set_lds(select_plan_kernel, lds)) return rc;
             ProfScope ps("select_plan", s);
-            select_plan_kernel<<<dim3((unsigned)sp.Cs, (unsigned)a.B), dim3(256), lds, s>>>(a.samp, sp, a.rules, a.flag, a.cnt, a.img_ovf, a.hist);
+            // one wave per list once there are thousands of lists of at most a few thousand samples
+            if ((int64_t)sp.Cs * a.B >= 4096 && sp.ns_cap <= 4096) {
+                if (int rc = set_lds(select_plan_kernel<64>, lds)) return rc;
+                select_plan_kernel<64><<<dim3((unsigned)sp.Cs, (unsigned)a.B), dim3(64), lds, s>>>(a.samp, sp, a.rules, a.flag, a.cnt, a.img_ovf, a.hist);
+            } else {
+                if (int rc = set_lds(select_plan_kernel<256>, lds)) return rc;
+                select_plan_kernel<256><<<dim3((unsigned)sp.Cs, (unsigned)a.B), dim3(256), lds, s>>>(a.samp, sp, a.rules, a.flag, a.cnt, a.img_ovf, a.hist);
+            }
             DETBOX_LAUNCH_CHECK();
         }
         const unsigned gx = (unsigned)sp.scan_gx;

@@ -856,3 +856,25 @@ def test_operators_do_not_depend_on_workspace_contents(D, oracle, dev):
             D.ops._POISON = False
     assert all(torch.equal(a, b) for a, b in zip(*results))
     assert int(results[0][2].min()) >= 0
+
+
+def test_select_many_short_segments(D, oracle, dev):
+    """Thousands of (image, class) segments with a few thousand anchors each take the one-wave-per-segment
+    forms of the planning and finalising kernels: same candidates as the oracle, image by image."""
+    O = oracle
+    g = torch.Generator().manual_seed(21)
+    B, P, C, k = 256, 4500, 21, 60                           # 5120 segments; P >= 4096 keeps the sampled path
+    scores = torch.softmax(torch.randn(B, P, C, generator=g) * 1.5, -1)
+    scores[3, :, 2] = (scores[3, :, 2] * 64).round() / 64     # heavy ties in one segment
+    scores[5, :, 1:] = 0.0                                    # an image without candidates
+    locs = torch.randn(B, P, 4, generator=g)
+    anchors = torch.rand(P, 4, generator=g) * 0.5 + 0.2
+    c, pb, ps, pc = hip_select(D, dev, scores, locs, anchors, D.ops.DECODE_CXCYWH, 1, 0, 0.02, k)
+    pick = [0, 3, 5, 100, 255]
+    want = oracle_select(O, scores[pick], locs[pick], anchors, 0, 1, 0, 0.02, k)
+    check_select(([pb[i] for i in pick], [ps[i] for i in pick], [pc[i] for i in pick]), want)
+    assert int(c.counts[5]) == 0
+    keep, kc = D.ops.nms_candidates(c, 0.45)
+    for i in (0, 100):
+        wk = O.batched_nms(pb[i], ps[i], pc[i], 0.45)
+        assert torch.equal(keep[i, :int(kc[i])].cpu(), wk)
