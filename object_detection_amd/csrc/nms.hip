@@ -673,20 +673,30 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == 256 
 
 // Exclusive scan of the kept counts of an image's segments; a negative count marks a segment the NMS
 // kernel refused (longer than max_segment) and turns the image's keep count into -1.
-__global__ __launch_bounds__(256) void nms_scan_kernel(const int32_t *__restrict__ kcount, int S,
-                                                       int32_t *__restrict__ koff, int32_t *__restrict__ keep_counts) {
-    const int b = blockIdx.x;
-    if (threadIdx.x != 0) return;
-    int acc = 0, bad = 0;
+__global__ __launch_bounds__(64) void nms_scan_kernel(const int32_t *__restrict__ kcount, int S,
+                                                      int32_t *__restrict__ koff, int32_t *__restrict__ keep_counts) {
+    const int b = blockIdx.x, lane = threadIdx.x;
     const int32_t *kc = kcount + (size_t)b * S;
     int32_t *ko = koff + (size_t)b * (S + 1);
-    for (int s = 0; s < S; ++s) {
-        const int c = kc[s];
-        ko[s] = acc;
-        if (c < 0) bad = 1; else acc += c;
+    int acc = 0, bad = 0;
+    for (int s0 = 0; s0 < S; s0 += 64) {              // one wave: 64 counts a trip, prefix sums by shuffles
+        const int s = s0 + lane;
+        int c = s < S ? kc[s] : 0;
+        if (c < 0) { bad = 1; c = 0; }
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(inc, o);
+            if (lane >= o) inc += up;
+        }
+        if (s < S) ko[s] = acc + inc - c;
+        acc += __shfl(inc, 63);
     }
-    ko[S] = acc;
-    keep_counts[b] = bad ? -1 : acc;
+    bad = __any(bad);
+    if (lane == 0) {
+        ko[S] = acc;
+        keep_counts[b] = bad ? -1 : acc;
+    }
 }
 
 // One stable merge level: neighbouring runs (each `group` class segments of one image) are merged
@@ -744,10 +754,22 @@ __global__ __launch_bounds__(MP_THREADS) void nms_merge_kernel(
     const int a0 = s_split[0], a1 = s_split[1];
     const int b0 = d0 - a0;
     const int na = a1 - a0, nb = (d1 - d0) - na;
-    for (int i = tid; i < na; i += MP_THREADS) s_in[i] = A[a0 + i];
-    for (int i = tid; i < nb; i += MP_THREADS) s_in[na + i] = Bp[b0 + i];
-    __syncthreads();
     const int nt = na + nb;
+    {   // all the loads of a thread are issued before the first one is needed
+        float2 v[MP_VT];
+#pragma unroll
+        for (int q = 0; q < MP_VT; ++q) {
+            const int i = tid + q * MP_THREADS;
+            v[q] = make_float2(0.f, 0.f);
+            if (i < nt) v[q] = i < na ? A[a0 + i] : Bp[b0 + (i - na)];
+        }
+#pragma unroll
+        for (int q = 0; q < MP_VT; ++q) {
+            const int i = tid + q * MP_THREADS;
+            if (i < nt) s_in[i] = v[q];
+        }
+    }
+    __syncthreads();
     const int t0 = min(tid * MP_VT, nt), t1 = min(t0 + MP_VT, nt);
     int lo = max(0, t0 - nb), hi = min(t0, na);
     while (lo < hi) {

@@ -938,8 +938,9 @@ __device__ inline float4 decode_box(const float *__restrict__ anchors, float4 l,
 //   2. anchor order: selected anchors set bits of a P-bit LDS bitmap; a popcount scan gives every
 //      selected anchor its rank, i.e. its output row inside the class segment;
 //   3. decode and write.
-template <int DECODE, int KPT>
-__global__ __launch_bounds__(256) void select_finalize_kernel(
+// BLK = 64: one wave per segment (no barrier ever waits), for thousands of short staging lists.
+template <int DECODE, int KPT, int BLK>
+__global__ __launch_bounds__(BLK) void select_finalize_kernel(
     SelParams sp, const SelRule *__restrict__ rules, const uint32_t *__restrict__ cnt,
     const unsigned long long *__restrict__ staging, const int32_t *__restrict__ seg_off,
     const float4 *__restrict__ locs, const float *__restrict__ anchors, int class_id_offset, int use_bitmap,
@@ -948,7 +949,7 @@ __global__ __launch_bounds__(256) void select_finalize_kernel(
     __shared__ uint32_t s_h[256];
     __shared__ unsigned long long s_lo, s_hi, s_cut;
     __shared__ uint32_t s_rem, s_state;
-    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_wsum[BLK / 64];
     const TileOfImage wg = xcd_affine_tile();         // the classes of one image share an L2: its locs are gathered once
     const int ci = wg.x, b = wg.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -974,7 +975,7 @@ __global__ __launch_bounds__(256) void select_finalize_kernel(
         unsigned long long k[KPT];                    // 0 marks an empty slot: every real key is >= 2^32
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
-            const int i = tid + j * 256;
+            const int i = tid + j * BLK;
             k[j] = i < n_stage ? st[i] : 0ull;
         }
         unsigned long long cutoff = 0ull;
@@ -992,7 +993,7 @@ __global__ __launch_bounds__(256) void select_finalize_kernel(
                 const unsigned long long span = hi - lo;
                 const int sb = span ? 64 - __clzll((long long)span) : 0;
                 const int sh = sb > 8 ? sb - 8 : 0;
-                s_h[tid] = 0u;
+                for (int i = tid; i < 256; i += BLK) s_h[i] = 0u;
                 __syncthreads();
 #pragma unroll
                 for (int j = 0; j < KPT; ++j)
@@ -1027,7 +1028,7 @@ __global__ __launch_bounds__(256) void select_finalize_kernel(
         const int words = (sp.P + 63) >> 6;
         unsigned long long *s_bm = s_dyn64;                             // [words]
         uint32_t *s_wp = reinterpret_cast<uint32_t *>(s_bm + words);    // [words] exclusive popcount prefix
-        for (int w = tid; w < words; w += 256) s_bm[w] = 0ull;
+        for (int w = tid; w < words; w += BLK) s_bm[w] = 0ull;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
@@ -1038,7 +1039,7 @@ __global__ __launch_bounds__(256) void select_finalize_kernel(
         }
         __syncthreads();
         // block-wide exclusive scan of per-word popcounts: each thread owns a contiguous run of words
-        const int wpt = (words + 255) >> 8;
+        const int wpt = (words + BLK - 1) / BLK;
         const int w0 = tid * wpt, w1 = min(words, w0 + wpt);
         uint32_t local = 0;
         for (int w = w0; w < w1; ++w) local += (uint32_t)__popcll(s_bm[w]);
@@ -1070,7 +1071,7 @@ __global__ __launch_bounds__(256) void select_finalize_kernel(
         for (int j = 0; j < KPT; ++j)
             if (rank[j] >= 0 && rank[j] < take) s_out[rank[j]] = k[j];
         __syncthreads();
-        for (int r = tid; r < take; r += 256) emit(r, s_out[r]);
+        for (int r = tid; r < take; r += BLK) emit(r, s_out[r]);
     } else {
         // very large P: sort the staged keys, cut, then sort the survivors by anchor index
         unsigned long long *s_k = s_dyn64;                              // [cap]
@@ -1481,19 +1482,24 @@ extern "C" int detbox_select_decode(int decode_mode, int activation, const float
         if (use_bitmap && lds < (size_t)top_k * 8) lds = (size_t)top_k * 8;      // the winners in rank order reuse the bitmap
         const float4 *l4 = reinterpret_cast<const float4 *>(locs);
         float4 *ob = reinterpret_cast<float4 *>(out_boxes);
-#define DETBOX_FIN(D, K)                                                                                          \
+        // one wave per segment once there are thousands of short staging lists (up to 16 keys per lane)
+        const bool one_wave = use_bitmap && cap <= 1024 && Cs * B >= 4096;
+#define DETBOX_FIN(D, K, BLKC)                                                                                    \
     {                                                                                                             \
-        if (int rc2 = set_lds(select_finalize_kernel<D, K>, lds)) return rc2;                                     \
-        select_finalize_kernel<D, K><<<grid, dim3(256), lds, s>>>(sp, rules, cnt, staging, out_seg_offsets, l4, anchors, \
-                                                                  class_id_offset, use_bitmap, ob, out_scores, out_class_ids); \
+        if (int rc2 = set_lds(select_finalize_kernel<D, K, BLKC>, lds)) return rc2;                               \
+        select_finalize_kernel<D, K, BLKC><<<grid, dim3(BLKC), lds, s>>>(sp, rules, cnt, staging, out_seg_offsets, l4, anchors, \
+                                                                         class_id_offset, use_bitmap, ob, out_scores, out_class_ids); \
     }
-#define DETBOX_FIN_K(D)                                    \
-    switch (cap / 256) {                                   \
-        case 2: DETBOX_FIN(D, 2) break;                    \
-        case 4: DETBOX_FIN(D, 4) break;                    \
-        case 8: DETBOX_FIN(D, 8) break;                    \
-        case 16: DETBOX_FIN(D, 16) break;                  \
-        default: DETBOX_FIN(D, 32) break;                  \
+#define DETBOX_FIN_K(D)                                        \
+    if (one_wave) {                                            \
+        if (cap <= 512) DETBOX_FIN(D, 8, 64)                   \
+        else DETBOX_FIN(D, 16, 64)                             \
+    } else switch (cap / 256) {                                \
+        case 2: DETBOX_FIN(D, 2, 256) break;                   \
+        case 4: DETBOX_FIN(D, 4, 256) break;                   \
+        case 8: DETBOX_FIN(D, 8, 256) break;                   \
+        case 16: DETBOX_FIN(D, 16, 256) break;                 \
+        default: DETBOX_FIN(D, 32, 256) break;                 \
     }
         if (decode_mode == DETBOX_DECODE_CXCYWH) { DETBOX_FIN_K(DETBOX_DECODE_CXCYWH) }
         else if (decode_mode == DETBOX_DECODE_YOLO) { DETBOX_FIN_K(DETBOX_DECODE_YOLO) }
