@@ -127,14 +127,16 @@ class Workload:
         m = self.model
         c = m.candidates(self.outputs(), 0.01, self.top_k)      # activation fused into the selection pass
         keep, kc = ops.nms_candidates(c, 0.45)
-        rows_ids, rows_vals, row_off = ops.pack_detections(c.boxes, c.scores, c.class_ids, keep, kc, self.ids, self.hw)
-        if world > 1:
+        if world == 1:
+            rows_ids, rows_vals, row_off = ops.pack_detections(c.boxes, c.scores, c.class_ids, keep, kc, self.ids, self.hw)
+        else:
             # the exchange step: this rank's detections as a compact message; the gather of the previous
             # batch's messages starts now, on a side stream, and overlaps this batch's kernels
             if self.exchange is None:
                 self.exchange = RowExchange(keep_results=False, root=self.exchange_root)
                 self.hdr_rows = ops.wire_header_rows(self.B)
-            wire = ops.pack_wire(c.boxes, c.scores, c.class_ids, keep, kc, self.ids, self.hw, self.B)
+            rows_ids, rows_vals, row_off, wire = ops.pack_detections(c.boxes, c.scores, c.class_ids, keep, kc, self.ids,
+                                                                     self.hw, wire_images_cap=self.B)
             self.exchange.submit(wire, self.B, self.hdr_rows)
         return targets, c, kc, rows_ids, rows_vals, row_off
 

@@ -207,6 +207,14 @@ int detbox_pack_wire(const float *boxes, const float *scores, const int64_t *cla
                      const int64_t *keep, const int32_t *keep_counts,
                      const int64_t *image_ids, const int32_t *image_sizes,
                      int64_t B, int64_t stride, int64_t images_cap, uint32_t *wire, void *stream);
+/* detbox_pack_detections and detbox_pack_wire in one pass over the kept rows (one gather feeds the result
+ * rows and the message).  No counterpart in the reference. */
+int detbox_pack_detections_wire(const float *boxes, const float *scores, const int64_t *class_ids,
+                                const int64_t *keep, const int32_t *keep_counts,
+                                const int64_t *image_ids, const int32_t *image_sizes,
+                                int64_t B, int64_t stride,
+                                int64_t *rows_ids, double *rows_vals, int32_t *row_offsets,
+                                int64_t images_cap, uint32_t *wire, void *stream);
 
 /* ---- per-kernel timing (HIP events on the launch stream) --------------------------------- */
 

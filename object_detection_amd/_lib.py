@@ -35,6 +35,7 @@ SIGNATURES = {
     'detbox_debug_stream_read': (_i32, [_p, _i64, _p, _i32, _p]),
     'detbox_wire_header_rows': (_i64, [_i64]),
     'detbox_pack_wire': (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p]),
+    'detbox_pack_detections_wire': (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _p, _p]),
     'detbox_profile_enable': (_i32, [_i32]),
     'detbox_profile_only': (_i32, [ctypes.c_char_p]),
     'detbox_profile_reset': (_i32, []),

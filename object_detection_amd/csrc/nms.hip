@@ -859,11 +859,14 @@ __global__ __launch_bounds__(ML_THREADS) void nms_merge_lds_kernel(
     }
 }
 
+// WIRE: the same rows also leave in the wire form described at pack_wire_kernel (one gather feeds both).
+template <bool WIRE>
 __global__ __launch_bounds__(256) void pack_detections_kernel(
     const float4 *__restrict__ boxes, const float *__restrict__ scores, const int64_t *__restrict__ cls,
     const int64_t *__restrict__ keep, const int32_t *__restrict__ keep_counts,
     const int64_t *__restrict__ image_ids, const int32_t *__restrict__ image_sizes, int B, long long stride,
-    int64_t *__restrict__ rows_ids, double *__restrict__ rows_vals, int32_t *__restrict__ row_offsets) {
+    int64_t *__restrict__ rows_ids, double *__restrict__ rows_vals, int32_t *__restrict__ row_offsets,
+    int hdr_rows, uint32_t *__restrict__ wire) {
     __shared__ int s_red[256];
     const TileOfImage wg = xcd_affine_tile();            // the gathers of one image stay in one L2
     const int b = wg.y, bx_ = wg.x;
@@ -881,10 +884,20 @@ __global__ __launch_bounds__(256) void pack_detections_kernel(
     if (bx_ == 0 && threadIdx.x == 0) {
         row_offsets[b] = row0;
         if (b == B - 1) row_offsets[B] = row0 + n;
+        if (WIRE) {
+            wire[2 + b] = (uint32_t)row0;
+            const unsigned long long id = (unsigned long long)image_ids[b];
+            wire[2 + (B + 1) + 2 * b] = (uint32_t)id;
+            wire[2 + (B + 1) + 2 * b + 1] = (uint32_t)(id >> 32);
+            wire[2 + (B + 1) + 2 * B + 2 * b] = (uint32_t)image_sizes[2 * b];
+            wire[2 + (B + 1) + 2 * B + 2 * b + 1] = (uint32_t)image_sizes[2 * b + 1];
+            if (b == B - 1) { wire[0] = (uint32_t)(row0 + n); wire[1] = (uint32_t)B; wire[2 + B] = (uint32_t)(row0 + n); }
+        }
     }
     // rows of this block are built in LDS and leave as contiguous 8-byte streams
     __shared__ double s_vals[256 * 5];
     __shared__ int64_t s_ids[256 * 2];
+    __shared__ uint32_t s_wire[WIRE ? 256 * 6 : 1];
     const int t0 = bx_ * blockDim.x;
     if (t0 >= n) return;
     const int nb = min(256, n - t0);
@@ -901,12 +914,24 @@ __global__ __launch_bounds__(256) void pack_detections_kernel(
         s_vals[5 * r + 1] = (double)bx.y * H;
         s_vals[5 * r + 2] = (double)(bx.z - bx.x) * W;
         s_vals[5 * r + 3] = (double)(bx.w - bx.y) * H;
-        s_vals[5 * r + 4] = (double)scores[base + k];
+        const float sc = scores[base + k];
+        s_vals[5 * r + 4] = (double)sc;
+        if (WIRE) {
+            uint32_t *w = s_wire + 6 * r;
+            w[0] = (uint32_t)s_ids[2 * r + 1];
+            w[1] = __float_as_uint(bx.x); w[2] = __float_as_uint(bx.y);
+            w[3] = __float_as_uint(bx.z); w[4] = __float_as_uint(bx.w);
+            w[5] = __float_as_uint(sc);
+        }
     }
     __syncthreads();
     const size_t r0 = (size_t)row0 + t0;
     for (int i = threadIdx.x; i < 5 * nb; i += 256) rows_vals[5 * r0 + i] = s_vals[i];
     for (int i = threadIdx.x; i < 2 * nb; i += 256) rows_ids[2 * r0 + i] = s_ids[i];
+    if (WIRE) {
+        uint32_t *out = wire + 6 * ((size_t)hdr_rows + r0);
+        for (int i = threadIdx.x; i < 6 * nb; i += 256) out[i] = s_wire[i];
+    }
 }
 
 // Wire form of the kept detections for the exchange between ranks: 32-bit words, six per row
@@ -1105,28 +1130,58 @@ extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scor
     return DETBOX_OK;
 }
 
-extern "C" int detbox_pack_detections(const float *boxes, const float *scores, const int64_t *class_ids,
-                                      const int64_t *keep, const int32_t *keep_counts,
-                                      const int64_t *image_ids, const int32_t *image_sizes,
-                                      int64_t B, int64_t stride,
-                                      int64_t *rows_ids, double *rows_vals, int32_t *row_offsets, void *stream) {
+extern "C" int64_t detbox_wire_header_rows(int64_t images_cap);
+
+namespace {
+int pack_rows(const float *boxes, const float *scores, const int64_t *class_ids, const int64_t *keep,
+              const int32_t *keep_counts, const int64_t *image_ids, const int32_t *image_sizes, int64_t B, int64_t stride,
+              int64_t *rows_ids, double *rows_vals, int32_t *row_offsets, int64_t images_cap, uint32_t *wire, void *stream) {
     DETBOX_CHECK_ARG(B >= 0 && stride >= 0, "negative size");
     DETBOX_CHECK_ARG(B <= 65535 && stride < (1ll << 31), "size too large");
     DETBOX_CHECK_ARG(row_offsets, "null pointer");
+    DETBOX_CHECK_ARG(!wire || images_cap >= B, "images_cap smaller than the number of images");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (B == 0 || stride == 0) {
         DETBOX_HIP(hipMemsetAsync(row_offsets, 0, (size_t)(B + 1) * sizeof(int32_t), st));
+        if (wire) DETBOX_HIP(hipMemsetAsync(wire, 0, (size_t)detbox_wire_header_rows(images_cap) * 6 * sizeof(uint32_t), st));
         return DETBOX_OK;
     }
     DETBOX_CHECK_ARG(boxes && scores && class_ids && keep && keep_counts && image_ids && image_sizes && rows_ids && rows_vals,
                      "null pointer");
     DETBOX_CHECK_ARG((uintptr_t)boxes % 16 == 0, "boxes must be 16-byte aligned");
     ProfScope ps("pack_detections", st);
-    pack_detections_kernel<<<dim3((unsigned)((stride + 255) / 256), (unsigned)B), dim3(256), 0, st>>>(
-        reinterpret_cast<const float4 *>(boxes), scores, class_ids, keep, keep_counts, image_ids, image_sizes, (int)B,
-        stride, rows_ids, rows_vals, row_offsets);
+    const dim3 grid((unsigned)((stride + 255) / 256), (unsigned)B);
+    const float4 *b4 = reinterpret_cast<const float4 *>(boxes);
+    if (wire)
+        pack_detections_kernel<true><<<grid, dim3(256), 0, st>>>(b4, scores, class_ids, keep, keep_counts, image_ids, image_sizes,
+                                                                 (int)B, stride, rows_ids, rows_vals, row_offsets,
+                                                                 (int)detbox_wire_header_rows(images_cap), wire);
+    else
+        pack_detections_kernel<false><<<grid, dim3(256), 0, st>>>(b4, scores, class_ids, keep, keep_counts, image_ids, image_sizes,
+                                                                  (int)B, stride, rows_ids, rows_vals, row_offsets, 0, nullptr);
     DETBOX_LAUNCH_CHECK();
     return DETBOX_OK;
+}
+}  // namespace
+
+extern "C" int detbox_pack_detections(const float *boxes, const float *scores, const int64_t *class_ids,
+                                      const int64_t *keep, const int32_t *keep_counts,
+                                      const int64_t *image_ids, const int32_t *image_sizes,
+                                      int64_t B, int64_t stride,
+                                      int64_t *rows_ids, double *rows_vals, int32_t *row_offsets, void *stream) {
+    return pack_rows(boxes, scores, class_ids, keep, keep_counts, image_ids, image_sizes, B, stride, rows_ids, rows_vals,
+                     row_offsets, 0, nullptr, stream);
+}
+
+extern "C" int detbox_pack_detections_wire(const float *boxes, const float *scores, const int64_t *class_ids,
+                                           const int64_t *keep, const int32_t *keep_counts,
+                                           const int64_t *image_ids, const int32_t *image_sizes,
+                                           int64_t B, int64_t stride,
+                                           int64_t *rows_ids, double *rows_vals, int32_t *row_offsets,
+                                           int64_t images_cap, uint32_t *wire, void *stream) {
+    DETBOX_CHECK_ARG(wire, "null pointer");
+    return pack_rows(boxes, scores, class_ids, keep, keep_counts, image_ids, image_sizes, B, stride, rows_ids, rows_vals,
+                     row_offsets, images_cap, wire, stream);
 }
 
 extern "C" int64_t detbox_wire_header_rows(int64_t images_cap) {

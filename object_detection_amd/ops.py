@@ -278,9 +278,11 @@ def nms_candidates(c: Candidates, iou_threshold: float) -> Tuple[torch.Tensor, t
     return nms_segments(c.boxes, c.scores, c.seg_offsets, iou_threshold, max_segment=c.top_k, presorted=False)
 
 
-def pack_detections(boxes, scores, class_ids, keep, keep_counts, image_ids: torch.Tensor, image_sizes: torch.Tensor):
+def pack_detections(boxes, scores, class_ids, keep, keep_counts, image_ids: torch.Tensor, image_sizes: torch.Tensor,
+                    wire_images_cap: Optional[int] = None):
     """-> rows_ids [B*stride,2] i64, rows_vals [B*stride,5] f64, row_offsets [B+1] i32 (rows beyond
-    row_offsets[B] are unused)."""
+    row_offsets[B] are unused).  With wire_images_cap the same pass also writes the message of pack_wire,
+    returned as a fourth value."""
     dev = boxes.device
     boxes, scores, class_ids, keep = _dense(boxes), _dense(scores), _dense(class_ids, torch.int64), _dense(keep, torch.int64)
     keep_counts, image_sizes = _dense(keep_counts, torch.int32), _dense(image_sizes.to(dev), torch.int32)
@@ -292,11 +294,21 @@ def pack_detections(boxes, scores, class_ids, keep, keep_counts, image_ids: torc
     rows_vals = torch.empty((B * stride, 5), dtype=torch.float64, device=dev)
     row_off = torch.empty((B + 1,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().detbox_pack_detections(_ptr(boxes), _ptr(scores), _ptr(class_ids), _ptr(keep),
-                                                     keep_counts.data_ptr(), image_ids.data_ptr(), image_sizes.data_ptr(),
-                                                     B, stride, rows_ids.data_ptr(), rows_vals.data_ptr(),
-                                                     row_off.data_ptr(), _stream(dev)), 'detbox_pack_detections')
-    return rows_ids, rows_vals, row_off
+        if wire_images_cap is None:
+            _lib.check(_lib.lib().detbox_pack_detections(_ptr(boxes), _ptr(scores), _ptr(class_ids), _ptr(keep),
+                                                         keep_counts.data_ptr(), image_ids.data_ptr(), image_sizes.data_ptr(),
+                                                         B, stride, rows_ids.data_ptr(), rows_vals.data_ptr(),
+                                                         row_off.data_ptr(), _stream(dev)), 'detbox_pack_detections')
+            return rows_ids, rows_vals, row_off
+        if B > wire_images_cap:
+            raise ValueError('pack_detections: more images than wire_images_cap')
+        wire = torch.empty((wire_header_rows(wire_images_cap) + B * stride, 6), dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().detbox_pack_detections_wire(_ptr(boxes), _ptr(scores), _ptr(class_ids), _ptr(keep),
+                                                          keep_counts.data_ptr(), image_ids.data_ptr(), image_sizes.data_ptr(),
+                                                          B, stride, rows_ids.data_ptr(), rows_vals.data_ptr(),
+                                                          row_off.data_ptr(), int(wire_images_cap), wire.data_ptr(),
+                                                          _stream(dev)), 'detbox_pack_detections_wire')
+    return rows_ids, rows_vals, row_off, wire
 
 
 class _FocalLossSum(torch.autograd.Function):

@@ -601,6 +601,11 @@ def test_wire_message_rebuilds_result_rows(D, oracle, dev):
         wire = D.ops.pack_wire(c.boxes, c.scores, c.class_ids, keep, kc, ids, hw, cap)
         gid, gv = unpack_wire(wire, hdr)
         assert torch.equal(gid, rid[:n]) and torch.equal(gv, rv[:n])
+        # the one-pass form writes the same rows and the same message
+        rid2, rv2, ro2, wire2 = D.ops.pack_detections(c.boxes, c.scores, c.class_ids, keep, kc, ids, hw, wire_images_cap=cap)
+        assert torch.equal(ro2, ro) and torch.equal(rid2[:n], rid[:n]) and torch.equal(rv2[:n], rv[:n])
+        assert torch.equal(wire2[:hdr + n].reshape(-1)[:2 + 5 * B + 1], wire[:hdr + n].reshape(-1)[:2 + 5 * B + 1])
+        assert torch.equal(wire2[hdr:hdr + n], wire[hdr:hdr + n])
         ex = RowExchange()
         ex.submit(wire, cap, hdr)
         ex.submit(wire, cap, hdr)
