@@ -64,7 +64,10 @@ def _dense(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[torch.Ten
     tensor of the right type, a copy for a strided view or a slice that starts off a 16-byte boundary."""
     if t is None:
         return None
-    t = t.to(dtype).contiguous()
+    if t.dtype is not dtype:
+        t = t.to(dtype)
+    if not t.is_contiguous():
+        t = t.contiguous()
     return t.clone() if t.data_ptr() % 16 else t
 
 
