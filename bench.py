@@ -26,6 +26,7 @@ sys.path.insert(0, REPO)
 import object_detection_amd as D  # noqa: E402
 from object_detection_amd import ops  # noqa: E402
 from object_detection_amd.dist import RowExchange  # noqa: E402
+from object_detection_amd.pipeline import StreamRing  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, spec
 
@@ -280,10 +281,9 @@ def main():
         torch.cuda.synchronize()
     streams = None
     if args.streams > 1 and graph is None:
-        streams = [torch.cuda.Stream(dev) for _ in range(args.streams)]
-        for st in streams:                            # workspaces and allocator pools of every stream exist before the clock starts
-            st.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(st):
+        streams = StreamRing(dev, args.streams)
+        for _ in range(len(streams)):                 # workspaces and allocator pools of every stream exist before the clock starts
+            with streams.next():
                 wl.step(world)
         torch.cuda.synchronize()
     barrier()
@@ -292,7 +292,7 @@ def main():
         if graph is not None:
             graph.replay()
         elif streams is not None:
-            with torch.cuda.stream(streams[i % len(streams)]):
+            with streams.next():
                 wl.step(world)
         else:
             wl.step(world)

@@ -83,15 +83,19 @@ class _BoxOps:
         return pb, ps, pc
 
     def detect(self, outputs: tuple, image_metas: Sequence[dict], conf_thresh: float = 0.01, top_k: int = 200,
-               iou_thresh: float = 0.45):
+               iou_thresh: float = 0.45, trim: bool = True):
         """pre_predict + Predictor.run on the device.  Returns (rows_ids [N,2] i64, rows_vals [N,5] f64)
-        device tensors; nothing is synchronised except the final row count."""
+        device tensors; nothing is synchronised except the final row count.  trim=False skips that one
+        synchronisation too and returns (rows_ids, rows_vals, row_offsets) with the buffers at full length
+        (rows beyond row_offsets[-1] unused) -- the form for batches in flight on several streams."""
         c = self.candidates(outputs, conf_thresh, top_k)
         keep, kc = ops.nms_candidates(c, iou_thresh)
         dev = c.boxes.device
         ids = torch.tensor([m['image_id'] for m in image_metas], dtype=torch.int64).to(dev, non_blocking=True)
         hw = torch.tensor([[m['height'], m['width']] for m in image_metas], dtype=torch.int32).to(dev, non_blocking=True)
         rows_ids, rows_vals, row_off = ops.pack_detections(c.boxes, c.scores, c.class_ids, keep, kc, ids, hw)
+        if not trim:
+            return rows_ids, rows_vals, row_off
         n = int(row_off[-1].item())
         return rows_ids[:n], rows_vals[:n]
 

@@ -883,3 +883,34 @@ def test_select_many_short_segments(D, oracle, dev):
     for i in (0, 100):
         wk = O.batched_nms(pb[i], ps[i], pc[i], 0.45)
         assert torch.equal(keep[i, :int(kc[i])].cpu(), wk)
+
+
+def test_batches_in_flight_on_alternating_streams(D, oracle, dev):
+    """Consecutive batches issued on a StreamRing (per-stream workspaces, no shared state) give exactly the
+    results of the same batches run one after the other on the current stream."""
+    g = torch.Generator().manual_seed(77)
+    P, C, k = 20000, 21, 100
+    anchors = (torch.rand(P, 4, generator=g) * 0.5 + 0.2).to(dev)
+    batches = [(torch.softmax(torch.randn(4, P, C, generator=g), -1).to(dev), torch.randn(4, P, 4, generator=g).to(dev))
+               for _ in range(6)]
+
+    def run(scores, locs):
+        c = D.ops.select_decode(scores, locs, anchors, D.ops.DECODE_CXCYWH, 1, 0, 0.02, k)
+        keep, kc = D.ops.nms_candidates(c, 0.45)
+        return c.counts, c.scores, c.boxes, keep, kc
+
+    want = [run(*b) for b in batches]
+    torch.cuda.synchronize()
+    ring = D.StreamRing(dev, 3)
+    got = []
+    for b in batches:
+        with ring.next():
+            got.append(run(*b))
+    ring.synchronize()
+    for w, gt in zip(want, got):
+        n = int(w[0].max())
+        assert torch.equal(w[0], gt[0]) and torch.equal(w[4], gt[4])
+        for i in range(4):
+            ni, ki = int(w[0][i]), int(w[4][i])
+            assert torch.equal(w[1][i, :ni], gt[1][i, :ni]) and torch.equal(w[2][i, :ni], gt[2][i, :ni])
+            assert torch.equal(w[3][i, :ki], gt[3][i, :ki])
