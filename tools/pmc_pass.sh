@@ -3,4 +3,4 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc1
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES --output-format csv -d $OUT/a -o a -- python3 $ROOT/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $OUT/a.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES --output-format csv -d $OUT/a -o a -- python3 $ROOT/bench.py --no-cpu-baseline --steps 2 --warmup 1 --streams 1 > $OUT/a.log 2>&1
