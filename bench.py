@@ -193,7 +193,7 @@ def main():
     ap.add_argument('--cpu-images', type=int, default=-1, help='images in the CPU baseline sample (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle timing (profiling runs)')
     ap.add_argument('--graph', action='store_true',
-                    help='N=1 only: capture one step in a HIP graph and replay it in the timed region (launch-bound workloads)')
+                    help='N=1 only: capture one step per stream in a HIP graph and replay it in the timed region (launch-bound workloads)')
     ap.add_argument('--streams', type=int, default=2,
                     help='steps are issued round-robin on this many HIP streams (independent batches in flight)')
     ap.add_argument('--exchange', default='root', choices=['root', 'all'],
@@ -265,23 +265,26 @@ def main():
     ops.profile_only(dom)
     ops.profile_enable(True)
     graph = None
+    streams = StreamRing(dev, args.streams) if args.streams > 1 else None
     if args.graph and world == 1:
-        # every launch of a step goes into one HIP graph (buffers come from the capture's private pool);
-        # a replay runs exactly the same kernels on the same inputs
+        # every launch of a step goes into one HIP graph per stream (buffers come from the capture's private
+        # pool, workspaces are per stream); a replay runs exactly the same kernels on the same inputs
         ops.profile_enable(False)
-        side = torch.cuda.Stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            wl.step(world)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            graph_out = wl.step(world)
-        graph.replay()
+        graph = []
+        for st in (streams.streams if streams is not None else [torch.cuda.Stream(dev)]):
+            st.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(st):
+                wl.step(world)
+            st.synchronize()
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_, stream=st):
+                graph_out = wl.step(world)
+            graph.append((g_, st, graph_out))
+        for g_, st, _ in graph:
+            with torch.cuda.stream(st):
+                g_.replay()
         torch.cuda.synchronize()
-    streams = None
-    if args.streams > 1 and graph is None:
-        streams = StreamRing(dev, args.streams)
+    elif streams is not None:
         for _ in range(len(streams)):                 # workspaces and allocator pools of every stream exist before the clock starts
             with streams.next():
                 wl.step(world)
@@ -290,7 +293,9 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         if graph is not None:
-            graph.replay()
+            g_, st, _ = graph[i % len(graph)]
+            with torch.cuda.stream(st):
+                g_.replay()
         elif streams is not None:
             with streams.next():
                 wl.step(world)
@@ -347,7 +352,7 @@ def main():
             'metric': 'images/sec assign+decode+NMS', 'value': ips, 'unit': 'images/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'launch': 'hip-graph replay' if graph is not None else ('stream' if streams is None else f'{len(streams)} streams, steps round-robin'),
+            'launch': (f'hip-graph replay on {len(graph)} stream(s)' if graph is not None else ('stream' if streams is None else f'{len(streams)} streams, steps round-robin')),
             'config': {'workload': f'{args.workload} {args.regime}: B={B}/GPU P={P} C={C} top_k={wl.top_k} conf>0.01 nms=0.45',
                        'images_per_gpu': B, 'global_batch': world * B, 'candidates_per_image': n_cand,
                        'kept_per_image': n_keep, 'gt_per_image': G_mean, 'parallelism': f'image-sharded x{world}', 'streams': (1 if streams is None else len(streams)), 'exchange': ('none' if world == 1 else ('gather to rank 0' if args.exchange == 'root' else 'all-gather'))},
