@@ -623,7 +623,10 @@ __global__ __launch_bounds__(256) void select_bucket_kernel(SelParams sp, const 
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < 4; ++w)
-        for (int e = tid; e < nw[w]; e += 256) atomicAdd(&s_ccount[(uint32_t)(list[w * wcap + e] >> 24) & 0xffu], 1u);
+        for (int e = tid; e < nw[w]; e += 256) {
+            const uint32_t ci = (uint32_t)(list[w * wcap + e] >> 24) & 0xffu;
+            if (ci < (uint32_t)Cs) atomicAdd(&s_ccount[ci], 1u);          // entries are the scan's own; the check costs nothing
+        }
     __syncthreads();
     if (tid < Cs) {
         const uint32_t c = s_ccount[tid];
@@ -637,6 +640,7 @@ __global__ __launch_bounds__(256) void select_bucket_kernel(SelParams sp, const 
         for (int e = tid; e < nw[w]; e += 256) {
             const unsigned long long en = list[w * wcap + e];
             const uint32_t ci = (uint32_t)(en >> 24) & 0xffu;
+            if (ci >= (uint32_t)Cs) continue;
             const uint32_t pos = s_cbase[ci] + atomicAdd(&s_ccount[ci], 1u);
             const uint32_t p = (uint32_t)en & 0xffffffu;
             if (pos < (uint32_t)cap)
