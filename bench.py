@@ -326,7 +326,10 @@ def main():
         achieved = alg_bytes[dom] / (dom_us * 1e-6) / 1e9
         roofline = dict(kernel=dom, bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
                         frac=achieved / HBM_PEAK_GBS, traffic=measured_traffic(args, dom), avg_us=dom_us,
-                        launches=n, algorithmic_bytes=alg_bytes[dom])
+                        launches=n, algorithmic_bytes=alg_bytes[dom],
+                        avg_us_one_batch_in_flight=kern[dom]['avg_us'],
+                        note='avg_us is measured in the timed region, where the kernel shares the CUs with the other '
+                             'batch in flight; avg_us_one_batch_in_flight comes from the single-stream survey pass')
         # the streaming kernel of the path (reads the logits once), from the survey pass
         streaming = None
         if 'select_scan' in kern:
