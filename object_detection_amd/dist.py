@@ -160,9 +160,8 @@ class RowExchange:
             else:
                 send = send.contiguous()
                 out = parts = None
-                if self.rank == self.root:
-                    out = torch.empty((self.world, rows, 6), dtype=torch.int32, device=wire.device)
-                    parts = list(out.unbind(0))
+                if self.rank == self.root:             # one buffer per sender, as dist.gather is most commonly given
+                    out = parts = [torch.empty((rows, 6), dtype=torch.int32, device=wire.device) for _ in range(self.world)]
                 work = dist.gather(send, parts, dst=self.root, group=self.group, async_op=True)
             if wire.is_cuda:
                 wire.record_stream(self.comm)
@@ -191,9 +190,10 @@ class RowExchange:
 
 
 def unpack_gathered(batch) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(out [world, rows, 6], header_rows, counts) of one batch -> rows of all ranks in rank order."""
+    """(out [world, rows, 6] or a list of world [rows, 6] messages, header_rows, counts) of one batch -> rows of
+    all ranks in rank order."""
     out, header_rows, counts = batch
     if out is None:
         raise ValueError('this rank did not receive the batch (RowExchange(root=...) delivers to the root only)')
-    parts = [unpack_wire(out[r], header_rows) for r in range(out.shape[0])]
+    parts = [unpack_wire(out[r], header_rows) for r in range(len(out))]
     return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
