@@ -154,15 +154,20 @@ class RowExchange:
             else:                                  # another rank has more rows than this buffer holds
                 send = torch.zeros((rows, 6), dtype=torch.int32, device=wire.device)
                 send[:wire.shape[0]] = wire
-            if self.root is None:
-                out = torch.empty((self.world, rows, 6), dtype=torch.int32, device=wire.device)
-                work = dist.all_gather_into_tensor(out.view(self.world * rows, 6), send, group=self.group, async_op=True)
-            else:
+            work = None
+            if self.root is not None:
                 send = send.contiguous()
                 out = parts = None
                 if self.rank == self.root:             # one buffer per sender, as dist.gather is most commonly given
                     out = parts = [torch.empty((rows, 6), dtype=torch.int32, device=wire.device) for _ in range(self.world)]
-                work = dist.gather(send, parts, dst=self.root, group=self.group, async_op=True)
+                try:
+                    work = dist.gather(send, parts, dst=self.root, group=self.group, async_op=True)
+                except (RuntimeError, NotImplementedError, ValueError):
+                    # a backend without gather refuses on every rank alike: deliver to all ranks from here on
+                    self.root = None
+            if self.root is None:
+                out = torch.empty((self.world, rows, 6), dtype=torch.int32, device=wire.device)
+                work = dist.all_gather_into_tensor(out.view(self.world * rows, 6), send, group=self.group, async_op=True)
             if wire.is_cuda:
                 wire.record_stream(self.comm)
         self.flying.append((work, out, header_rows, counts, send))
