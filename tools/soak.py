@@ -127,8 +127,49 @@ def soak_assign(g):
     return ok, dict(kind='assign', fam=fam, B=B)
 
 
+def soak_select_many(g):
+    """Thousands of short segments: the one-wave-per-segment forms of the planning and finalising kernels."""
+    B = int(torch.randint(210, 420, (1,), generator=g))
+    P = int(torch.randint(4096, 7000, (1,), generator=g))
+    C = int(torch.randint(21, 30, (1,), generator=g))
+    k = int(torch.randint(20, 260, (1,), generator=g))
+    thr = [0.01, 0.03][int(torch.randint(0, 2, (1,), generator=g))]
+    scale = float(torch.rand(1, generator=g) * 2 + 0.5)
+    scores = torch.softmax(torch.randn(B, P, C, generator=g) * scale, -1)
+    if int(torch.randint(0, 2, (1,), generator=g)):
+        scores = (scores * 256).round() / 256                    # ties
+    locs = torch.randn(B, P, 4, generator=g)
+    anchors = torch.rand(P, 4, generator=g) * 0.5 + 0.2
+    c = D.ops.select_decode(scores.to(dev), locs.to(dev), anchors.to(dev), D.ops.DECODE_CXCYWH, 1, 0, thr, k)
+    ok = True
+    for b in torch.randint(0, B, (4,), generator=g).tolist():
+        wb, ws, wc = O.select_decode_fast(locs[b], scores[b], anchors, thr, k, 'cxcywh', 1, 0)
+        n = int(c.counts[b])
+        ok = ok and n == ws.numel() and torch.equal(c.scores[b, :n].cpu(), ws) and torch.equal(c.class_ids[b, :n].cpu(), wc) \
+            and close(c.boxes[b, :n].cpu(), wb)
+    return ok, dict(kind='select_many', B=B, P=P, C=C, k=k, thr=thr)
+
+
+def soak_assign_large(g):
+    """Batches large enough for the four-anchors-per-thread form of the assignment kernel."""
+    m = D.RetinaNet(20, [64, 32, 16, 8, 4])
+    P = m.pboxes.shape[0]
+    B = (1 << 20) // P + 1 + int(torch.randint(0, 6, (1,), generator=g))
+    gts = []
+    for _ in range(B):
+        G = int(torch.randint(1, 70, (1,), generator=g))
+        c = 0.1 + 0.8 * torch.rand(G, 2, generator=g)
+        wh = 0.01 + 0.6 * torch.rand(G, 2, generator=g)
+        gts.append((torch.cat([c, wh], 1), torch.randint(1, 21, (G,), generator=g)))
+    got = m.assign([q[0] for q in gts], [q[1] for q in gts], dev)
+    want = O.assign_retinanet(m.pboxes, [q[0] for q in gts], [q[1] for q in gts])
+    ok = torch.equal(got[1].cpu(), want[1]) and torch.equal(got[2].cpu(), want[2]) and close(got[0].cpu(), want[0])
+    return ok, dict(kind='assign_large', B=B, P=P)
+
+
 def main():
-    for name, fn in (('nms', soak_nms), ('select', soak_select), ('assign', soak_assign)):
+    for name, fn in (('nms', soak_nms), ('select', soak_select), ('assign', soak_assign),
+                     ('select_many', soak_select_many), ('assign_large', soak_assign_large)):
         g = torch.Generator().manual_seed(SEED * 1000 + hash(name) % 997)
         t0, n = time.time(), 0
         last = t0
