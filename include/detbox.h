@@ -120,6 +120,18 @@ int detbox_focal_loss_forward(const float *logits, const int64_t *labels, int64_
 int detbox_focal_loss_backward(const float *logits, const int64_t *labels, int64_t rows, int64_t C,
                                float alpha, float gamma, const float *grad_scale, float *grad_logits, void *stream);
 
+/* Localisation loss of the SSD and RetinaNet heads with its mask, summed:
+ *   F.smooth_l1_loss(out_locs[pos_mask], target_locs[pos_mask], reduction='sum'),  pos_mask = labels > 0
+ * (src/models/ssd300.py:283, src/models/retinanet.py:211; beta = 1).  input, target [rows, 4], labels [rows];
+ * *loss_sum (device, float64) receives the sum.  The backward call writes grad_input [rows, 4] =
+ * *grad_scale * d(sum)/d(input) (zero rows where labels <= 0); grad_scale is a device scalar.
+ * Floating point: every term is the reference's fp32 value, the sum is accumulated in float64 (tested to
+ * 1e-5 relative against the reference's fp32 sum). */
+int detbox_smooth_l1_masked_forward(const float *input, const float *target, const int64_t *labels,
+                                    int64_t rows, double *loss_sum, void *stream);
+int detbox_smooth_l1_masked_backward(const float *input, const float *target, const int64_t *labels,
+                                     int64_t rows, const float *grad_scale, float *grad_input, void *stream);
+
 /* ---- inference: activation + threshold + exact top-k + decode ---------------------------- */
 
 /* activations applied to the head output before the threshold */
@@ -224,7 +236,8 @@ int detbox_pack_detections_wire(const float *boxes, const float *scores, const i
  * "box_iou", "assign_anchor", "assign_fixup", "assign_fcos", "activate_scores", "select_sample",
  * "select_plan", "select_scan", "select_bucket", "select_check", "select_materialize", "score_hist", "select_kth",
  * "select_refine", "select_emit", "select_finalize", "nms_segments", "nms_scan", "nms_merge",
- * "nms_write", "pack_detections", "pack_wire", "topk_mask", "focal_forward", "focal_backward". */
+ * "nms_write", "pack_detections", "pack_wire", "topk_mask", "focal_forward", "focal_backward",
+ * "smooth_l1_forward", "smooth_l1_backward". */
 int detbox_profile_enable(int on);
 /* Restricts the timing to the one kernel called `name` (NULL or "" = every kernel again), so that a
  * timed run pays the event overhead for that kernel only. */

@@ -25,6 +25,8 @@ SIGNATURES = {
     'detbox_topk_mask': (_i32, [_p, _p, _i64, _i64, _p, _p]),
     'detbox_focal_loss_forward': (_i32, [_p, _p, _i64, _i64, _f32, _f32, _p, _p]),
     'detbox_focal_loss_backward': (_i32, [_p, _p, _i64, _i64, _f32, _f32, _p, _p, _p]),
+    'detbox_smooth_l1_masked_forward': (_i32, [_p, _p, _p, _i64, _p, _p]),
+    'detbox_smooth_l1_masked_backward': (_i32, [_p, _p, _p, _i64, _p, _p, _p]),
     'detbox_activate_scores': (_i32, [_i32, _p, _p, _i64, _i64, _i64, _p, _p]),
     'detbox_select_decode_workspace_bytes': (_sz, [_i64, _i64, _i64, _i32, _i32, _i32]),
     'detbox_select_decode': (_i32, [_i32, _i32, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _f32,

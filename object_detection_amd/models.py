@@ -133,7 +133,7 @@ class SSD300(_BoxOps):
         loss_neg[pos_mask] = 0
         neg_mask = ops.topk_mask(loss_neg, 3 * pos_mask.sum(dim=1))      # hard-negative mining, ssd300.py:277-278
         N = pos_mask.sum()
-        loss_loc = F.smooth_l1_loss(out_locs[pos_mask], target_locs[pos_mask], reduction='sum') / N
+        loss_loc = ops.smooth_l1_masked_sum(out_locs, target_locs, target_labels) / N      # ssd300.py:283, fused with the mask
         # Step 4 (ssd300.py:288): cross entropy over positives and mined negatives = the fused focal sum with
         # alpha = 1, gamma = 0; every other row carries the ignore label
         sel_labels = torch.where(pos_mask | neg_mask, target_labels, torch.full_like(target_labels, -1))
@@ -180,7 +180,7 @@ class RetinaNet(_BoxOps):
         pos_mask = target_labels > 0
         neg_mask = target_labels == 0
         N = pos_mask.sum()
-        loss_loc = F.smooth_l1_loss(out_locs[pos_mask], target_locs[pos_mask], reduction='sum') / N
+        loss_loc = ops.smooth_l1_masked_sum(out_locs, target_locs, target_labels) / N      # retinanet.py:211, fused with the mask
         # Step 4 fused: rows with label -1 (ignored) are skipped inside the kernel (retinanet.py:215)
         loss_conf = ops.focal_loss_sum(out_confs, target_labels) / N
         return {'loss': loss_conf + loss_loc, 'loss_loc': loss_loc, 'loss_conf': loss_conf}

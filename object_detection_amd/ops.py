@@ -354,6 +354,47 @@ def focal_loss_sum(logits: torch.Tensor, labels: torch.Tensor, alpha: float = 0.
     return _FocalLossSum.apply(logits, labels, alpha, gamma)
 
 
+class _SmoothL1MaskedSum(torch.autograd.Function):
+    """sum over rows with label > 0 of smooth_l1(input, target) (beta = 1), fused with the mask: no nonzero(),
+    no [N_pos, 4] gathers, no host synchronisation."""
+
+    @staticmethod
+    def forward(ctx, input, target, labels):
+        dev = input.device
+        x = _dense(input.detach().reshape(-1, 4))
+        y = _dense(target.detach().to(dev).reshape(-1, 4))
+        t = _dense(labels.to(dev).reshape(-1), torch.int64)
+        if y.shape != x.shape or t.numel() != x.shape[0]:
+            raise ValueError('smooth_l1_masked_sum: input, target [..., 4] and labels [...] do not fit')
+        out = torch.empty((), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().detbox_smooth_l1_masked_forward(_ptr(x), _ptr(y), _ptr(t), x.shape[0], out.data_ptr(),
+                                                                  _stream(dev)), 'detbox_smooth_l1_masked_forward')
+        ctx.save_for_backward(x, y, t)
+        ctx.shape, ctx.dtype = input.shape, input.dtype
+        return out.to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, y, t = ctx.saved_tensors
+        dev = x.device
+        gs = grad_out.detach().to(device=dev, dtype=torch.float32).reshape(1).contiguous()
+        grad = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().detbox_smooth_l1_masked_backward(_ptr(x), _ptr(y), _ptr(t), x.shape[0], gs.data_ptr(),
+                                                                   _ptr(grad), _stream(dev)), 'detbox_smooth_l1_masked_backward')
+        return grad.reshape(ctx.shape).to(ctx.dtype), None, None
+
+
+def smooth_l1_masked_sum(input: torch.Tensor, target: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """F.smooth_l1_loss(input[labels > 0], target[labels > 0], reduction='sum') of the reference
+    (src/models/ssd300.py:283, src/models/retinanet.py:211), differentiable in `input`.
+    input, target [..., 4] on the GPU, labels [...]."""
+    if not input.is_cuda:
+        raise _lib.DetboxError('smooth_l1_masked_sum runs on a ROCm device only')
+    return _SmoothL1MaskedSum.apply(input, target, labels)
+
+
 def wire_header_rows(images_cap: int) -> int:
     return int(_lib.lib().detbox_wire_header_rows(int(images_cap)))
 

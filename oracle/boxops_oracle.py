@@ -612,3 +612,11 @@ def focal_loss_sum(logits: torch.Tensor, labels: torch.Tensor, alpha: float = 0.
     pt = F.softmax(x, dim=-1)
     log_pt = F.log_softmax(x, dim=-1)
     return F.nll_loss(alpha * (1 - pt).pow(gamma) * log_pt, t, reduction='sum')
+
+
+def smooth_l1_masked_sum(input: torch.Tensor, target: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """src/models/ssd300.py:283 and src/models/retinanet.py:211:
+    F.smooth_l1_loss(out_locs[pos_mask], target_locs[pos_mask], reduction='sum') with pos_mask = labels > 0."""
+    import torch.nn.functional as F
+    pos = labels > 0
+    return F.smooth_l1_loss(input[pos], target[pos], reduction='sum')

@@ -914,3 +914,30 @@ def test_batches_in_flight_on_alternating_streams(D, oracle, dev):
             ni, ki = int(w[0][i]), int(w[4][i])
             assert torch.equal(w[1][i, :ni], gt[1][i, :ni]) and torch.equal(w[2][i, :ni], gt[2][i, :ni])
             assert torch.equal(w[3][i, :ki], gt[3][i, :ki])
+
+
+def test_smooth_l1_masked_fused_forward_backward(D, oracle, dev):
+    """Fused masked smooth-L1 sum against the oracle's restatement of src/models/ssd300.py:283 /
+    src/models/retinanet.py:211, value and gradient.  Floating point: every term is the fp32 value torch
+    computes, the sum is accumulated in float64 (the reference sums in fp32): 1e-5 relative on the sum; the
+    gradient entries are exact up to the upstream factor (1e-6 relative)."""
+    O = oracle
+    g = torch.Generator().manual_seed(12)
+    for shape, frac in (((1, 1), 1.0), ((3, 777), 0.05), ((16, 8732), 0.01), ((2, 120087), 0.002), ((4, 500), 0.0)):
+        B, P = shape
+        x = (1.5 * torch.randn(B, P, 4, generator=g)).requires_grad_(True)
+        y = torch.randn(B, P, 4, generator=g)
+        y[0, 0] = x.detach()[0, 0] + torch.tensor([1.0, -1.0, 0.0, 0.999999])          # the kinks of the function
+        lab = torch.where(torch.rand(B, P, generator=g) < frac, torch.randint(1, 21, (B, P), generator=g),
+                          torch.randint(-1, 1, (B, P), generator=g))
+        if frac > 0:
+            lab[0, 0] = 3
+        want = O.smooth_l1_masked_sum(x, y, lab)
+        (want / 9.0).backward()
+        xg = x.detach().to(dev).requires_grad_(True)
+        got = D.ops.smooth_l1_masked_sum(xg, y.to(dev), lab.to(dev))
+        (got / 9.0).backward()
+        assert abs(float(got.detach()) - float(want.detach())) <= 1e-5 * max(abs(float(want.detach())), 1e-6), shape
+        wgrad = x.grad if x.grad is not None else torch.zeros_like(x)
+        assert float((xg.grad.cpu() - wgrad).abs().max()) <= 1e-6 * max(float(wgrad.abs().max()), 1e-12), shape
+        assert bool((xg.grad.cpu()[lab <= 0] == 0).all())

@@ -139,3 +139,27 @@ def test_focal_loss_matches_reference(oracle):
     d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'focal_retinanet_small.npz'))
     got = oracle.focal_loss_sum(torch.from_numpy(d['out_confs']), torch.from_numpy(d['target_labels'])) / int(d['num_pos'])
     assert abs(float(got) - float(d['loss_conf'])) <= 1e-6 * abs(float(d['loss_conf']))
+
+
+def test_smooth_l1_matches_reference(oracle):
+    """loss_loc as the reference's own SSD300.loss / RetinaNet.loss returned it (tests/golden/loss_values.json):
+    the oracle's assignment feeds the oracle's masked smooth-L1 on the same seeded head outputs."""
+    import json
+    import os
+    O = oracle
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'loss_values.json')) as f:
+        cases = json.load(f)['cases']
+    tables = {'ssd300': (O.ssd300_default_boxes(), O.assign_ssd),
+              'retinanet_small': (O.retinanet_prior_boxes([8, 4, 2, 1, 1]), O.assign_retinanet)}
+    for name, (table, assign) in tables.items():
+        case = cases[name]
+        g = torch.Generator().manual_seed(case['seed'])
+        P = case['P']
+        assert table.shape[0] == P
+        locs = torch.randn(2, P, 4, generator=g)
+        gts = [O.synth_gt(i, 20, False, **case['gt_kw']) for i in case['gt_images']]
+        target_locs, target_labels = assign(table, [q[0] for q in gts], [q[1] for q in gts])[:2]
+        n_pos = int((target_labels > 0).sum())
+        got = O.smooth_l1_masked_sum(locs, target_locs, target_labels) / n_pos
+        want = case['loss']['loss_loc']
+        assert abs(float(got) - want) <= 1e-6 * abs(want), (name, float(got), want)
