@@ -1,6 +1,7 @@
-"""Randomised parity soak of the HIP path against the CPU oracle (development aid, run on the GPU box):
+"""Randomised parity soak of the HIP path against the CPU oracle (test infrastructure, not collected by pytest;
+run on the GPU box):
 
-    python tools/soak.py [seconds per category] [seed]
+    python tests/soak.py [seconds per category] [seed]
 
 Draws shapes, thresholds and score distributions at random for NMS, selection and assignment and compares
 every result with the oracle (bit-exact indices / labels / keep lists, 1e-5 on coordinates).  Prints a
