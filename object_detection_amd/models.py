@@ -76,10 +76,23 @@ class _BoxOps:
     def pre_predict(self, outputs: tuple, conf_thresh: float = 0.01, top_k: int = 200) -> tuple:
         c = self.candidates(outputs, conf_thresh, top_k)
         counts = c.counts.tolist()                      # the one device->host sync
-        dev = torch.device('cpu') if self.return_cpu else c.boxes.device
-        pb = [c.boxes[b, :n].to(dev) for b, n in enumerate(counts)]
-        ps = [c.scores[b, :n].to(dev) for b, n in enumerate(counts)]
-        pc = [c.class_ids[b, :n].to(dev) for b, n in enumerate(counts)]
+        boxes, scores, cls = c.boxes, c.scores, c.class_ids
+        if self.return_cpu:
+            if 2 * sum(counts) >= scores.numel():       # mostly full: three large copies instead of 3 * B small ones
+                boxes, scores, cls = boxes.cpu(), scores.cpu(), cls.cpu()
+                pb = [boxes[b, :n] for b, n in enumerate(counts)]
+                ps = [scores[b, :n] for b, n in enumerate(counts)]
+                pc = [cls[b, :n] for b, n in enumerate(counts)]
+            else:
+                pb = [boxes[b, :n].cpu() for b, n in enumerate(counts)]
+                ps = [scores[b, :n].cpu() for b, n in enumerate(counts)]
+                pc = [cls[b, :n].cpu() for b, n in enumerate(counts)]
+        else:
+            pb = [boxes[b, :n] for b, n in enumerate(counts)]
+            ps = [scores[b, :n] for b, n in enumerate(counts)]
+            pc = [cls[b, :n] for b, n in enumerate(counts)]
+        from . import predictor
+        predictor.remember((pb, ps, pc), c)              # Predictor.run continues on the device copy if handed these back
         return pb, ps, pc
 
     def detect(self, outputs: tuple, image_metas: Sequence[dict], conf_thresh: float = 0.01, top_k: int = 200,

@@ -17,6 +17,29 @@ from . import ops
 from ._lib import DetboxError
 
 
+# The lists pre_predict handed out last, with the device-resident candidates they were copied from.  When
+# Predictor.run is given those very lists back, unmodified (the flow of src/test.py:93-99), it continues on the
+# device copy instead of uploading and re-segmenting what just came down.
+_resident = None
+
+
+def remember(lists, candidates) -> None:
+    global _resident
+    pb, ps, pc = lists
+    _resident = (pb, ps, pc, [t._version for t in (*pb, *ps, *pc)], candidates)
+
+
+def recall(pb, ps, pc):
+    r = _resident
+    if r is None or r[0] is not pb or r[1] is not ps or r[2] is not pc:
+        return None
+    c = r[4]
+    B = c.boxes.shape[0]
+    if not (len(pb) == len(ps) == len(pc) == B) or [t._version for t in (*pb, *ps, *pc)] != r[3]:
+        return None
+    return c
+
+
 def rows_to_dicts(rows_ids: torch.Tensor, rows_vals: torch.Tensor) -> List[dict]:
     """[N,2] i64 + [N,5] f64 -> the reference's list of dicts (src/utilities/predictor.py:62-72)."""
     ids, vals = rows_ids.tolist(), rows_vals.tolist()
@@ -35,6 +58,18 @@ class Predictor:
         dev = pred_bboxes[0].device if B and pred_bboxes[0].is_cuda else ops._device()
         if B == 0:
             return (torch.zeros((0, 2), dtype=torch.int64, device=dev), torch.zeros((0, 5), dtype=torch.float64, device=dev))
+        c = recall(pred_bboxes, pred_scores, pred_class_ids)
+        if c is not None and c.boxes.shape[0] == B:
+            dev = c.boxes.device
+            with torch.cuda.device(dev):
+                keep, kc = ops.nms_candidates(c, self.iou_thresh)
+                ids = torch.tensor([m['image_id'] for m in image_metas], dtype=torch.int64).to(dev, non_blocking=True)
+                hw = torch.tensor([[m['height'], m['width']] for m in image_metas], dtype=torch.int32).to(dev, non_blocking=True)
+                rows_ids, rows_vals, row_off = ops.pack_detections(c.boxes, c.scores, c.class_ids, keep, kc, ids, hw)
+                n = int(row_off[-1].item())
+                if bool((kc < 0).any().item()):
+                    raise DetboxError('NMS reported an over-long segment')
+                return rows_ids[:n], rows_vals[:n]
         counts = [int(s.shape[0]) for s in pred_scores]
         n_max = max(max(counts), 1)
         with torch.cuda.device(dev):

@@ -941,3 +941,28 @@ def test_smooth_l1_masked_fused_forward_backward(D, oracle, dev):
         wgrad = x.grad if x.grad is not None else torch.zeros_like(x)
         assert float((xg.grad.cpu() - wgrad).abs().max()) <= 1e-6 * max(float(wgrad.abs().max()), 1e-12), shape
         assert bool((xg.grad.cpu()[lab <= 0] == 0).all())
+
+
+def test_predictor_continues_on_the_device_copy(D, oracle, dev):
+    """Predictor.run given back the very lists pre_predict returned continues on the device-resident candidates;
+    given copies (or modified tensors) it takes the generic path.  Both give the same rows; a modification is
+    honoured."""
+    from object_detection_amd import predictor as PR
+    g = torch.Generator().manual_seed(3)
+    m = D.SSD300(20)
+    P = m.dboxes.shape[0]
+    outs = (torch.randn(3, P, 4, generator=g).to(dev), (2.0 * torch.randn(3, P, 21, generator=g)).to(dev))
+    metas = [{'image_id': 10 + i, 'height': 300 + i, 'width': 400} for i in range(3)]
+    pb, ps, pc = m.pre_predict(outs, 0.05, 100)
+    assert PR.recall(pb, ps, pc) is not None
+    pred = D.Predictor(0.45)
+    fast = pred.run(metas, pb, ps, pc)
+    generic = pred.run(metas, [t.clone() for t in pb], [t.clone() for t in ps], [t.clone() for t in pc])
+    assert len(fast) > 0 and fast == generic
+    want = oracle.predictor_run(metas, pb, ps, pc, 0.45)
+    assert [(r['image_id'], r['category_id']) for r in fast] == [(r['image_id'], r['category_id']) for r in want]
+    ps[1][0] = 0.999                                          # an in-place edit: the device copy no longer applies
+    assert PR.recall(pb, ps, pc) is None
+    edited = pred.run(metas, pb, ps, pc)
+    assert edited == pred.run(metas, [t.clone() for t in pb], [t.clone() for t in ps], [t.clone() for t in pc])
+    assert any(abs(r['score'] - 0.999) < 1e-6 for r in edited)
