@@ -294,6 +294,87 @@ def test_select_nms_pack_match_golden(D, oracle, dev, name, table):
     assert [r['bbox'] + [r['score']] for r in res] == z['rows_vals'].tolist()
 
 
+def golden_model(D, spec):
+    """The model class of a predict_* fixture."""
+    nfg = spec['C'] - 1
+    if spec['family'] == 'ssd300':
+        return D.SSD300(nfg)
+    if spec['family'] == 'fcos':
+        return D.FCOS(nfg, spec['f_k'])
+    return D.RetinaNet(nfg, spec['f_k'])
+
+
+def from_logits_reports(D, dev, m, outs_cpu, thr, k, ref_lists, ref_keeps):
+    """Runs the shipped path on raw head outputs and compares it, image by image, with a reference result for
+    the same logits (golden rows or the CPU oracle): see e2e_compare.  Returns (reports, lists, keeps)."""
+    import e2e_compare as E
+    outs = tuple(o.to(dev) for o in outs_cpu)
+    pb, ps, pc = m.pre_predict(tuple(o.clone() for o in outs), thr, k)
+    c = m.candidates(tuple(o.clone() for o in outs), thr, k)
+    keep, kc = D.ops.nms_candidates(c, 0.45)
+    assert bool((kc >= 0).all())
+    keeps = [keep[b, :n].cpu() for b, n in enumerate(kc.cpu().tolist())]
+    _, hip_scores = m._activate(tuple(o.clone() for o in outs))        # the very scores the fused kernels rank
+    hip_scores = hip_scores.cpu()
+    ref_scores = torch_activation(m, outs_cpu)
+    assert rel_close(hip_scores, ref_scores, RTOL, atol=1e-9)
+    rb, rs, rc = ref_lists
+    reports = []
+    for b in range(len(rb)):
+        reports.append(E.compare_image(ref_scores[b], hip_scores[b], dict(boxes=rb[b], scores=rs[b], keep=ref_keeps[b]),
+                                       dict(boxes=pb[b], scores=ps[b], keep=keeps[b]), m.class_begin, thr, k, 0.45))
+    return reports, (pb, ps, pc), keeps
+
+
+@pytest.mark.parametrize('name,table', PREDICT)
+def test_from_logits_end_to_end_matches_golden(D, oracle, dev, name, table):
+    """The product path exactly as shipped -- raw head outputs through pre_predict (activation fused with the
+    kernel's own exp, HIP-decoded boxes) -> Predictor.run, and through detect() -- against the rows the
+    reference itself produced from the same logits on the CPU (ssd300.py:339-384 / fcos.py:299-343 ->
+    predictor.py:38-83).  Scores and coordinates agree to 1e-5.  Candidate sets and keep lists are identical
+    except where the reference's own decision sits on a rounding boundary (a score within 1e-5 of conf_thresh or of
+    the k-th score, two scores within 1e-5 of each other, an IoU within 1e-4 of the NMS threshold): every
+    difference is traced to such a boundary, and an image without one must match row for row."""
+    import e2e_compare as E
+    z = load('predict_' + name)
+    anchors = tables(D.anchors)[table]()
+    spec, locs, confs, ext = predict_inputs(z, anchors.shape[0])
+    m = golden_model(D, spec)
+    assert sha(m._anchors_for_decode()) == str(z['anchors_sha256'])
+    outs_cpu = (locs, confs) + ((ext,) if ext is not None else ())
+    counts = z['counts'].tolist()
+    metas = json.loads(str(z['metas']))
+    thr, k = spec['conf_thresh'], spec['top_k']
+    ref_lists = (split(torch.from_numpy(z['bboxes']), counts), split(torch.from_numpy(z['scores']), counts),
+                 split(torch.from_numpy(z['class_ids'].astype(np.int64)), counts))
+    ref_keeps = split(torch.from_numpy(z['keeps'].astype(np.int64)), z['keep_counts'].tolist())
+    reports, (pb, ps, pc), keeps = from_logits_reports(D, dev, m, outs_cpu, thr, k, ref_lists, ref_keeps)
+    print(name, E.summarise(reports), [r['first_divergence'] for r in reports])
+    assert not any(r['unexplained'] for r in reports), [r['unexplained'] for r in reports]
+
+    # images on which no boundary was crossed match the reference row for row
+    outs = tuple(o.to(dev) for o in outs_cpu)
+    res = D.Predictor(iou_thresh=0.45).run(metas, pb, ps, pc)
+    rid, rv = m.detect(tuple(o.clone() for o in outs), metas, thr, k)
+    got_ids = torch.tensor([[r['image_id'], r['category_id']] for r in res], dtype=torch.int64).reshape(-1, 2)
+    got_vals = torch.tensor([r['bbox'] + [r['score']] for r in res], dtype=torch.float64).reshape(-1, 5)
+    assert torch.equal(rid.cpu(), got_ids) and torch.equal(rv.cpu(), got_vals)     # detect() == pre_predict -> Predictor.run
+    want_ids, want_vals = torch.from_numpy(z['rows_ids']), torch.from_numpy(z['rows_vals'])
+    go, wo = 0, 0
+    for b, r in enumerate(reports):
+        gn, wn = keeps[b].numel(), int(z['keep_counts'][b])
+        if r['selection_diff'] == 0 and r['keep_differing'] == 0:
+            assert torch.equal(pc[b], ref_lists[2][b]) and box_close(pb[b], ref_lists[0][b], RTOL)
+            assert rel_close(ps[b], ref_lists[1][b], RTOL, atol=0.0)
+            assert torch.equal(got_ids[go:go + gn], want_ids[wo:wo + wn])
+            gv, wv = got_vals[go:go + gn], want_vals[wo:wo + wn]
+            # x, y, w, h: w and h are differences of coordinates, so the bound is relative to the box's far corner
+            far = (wv[:, 0] + wv[:, 2]).abs().maximum((wv[:, 1] + wv[:, 3]).abs()).clamp(min=1e-30)
+            assert bool(((gv[:, :4] - wv[:, :4]).abs() <= 4 * RTOL * far[:, None]).all())
+            assert rel_close(gv[:, 4], wv[:, 4], RTOL, atol=0.0)
+        go, wo = go + gn, wo + wn
+
+
 def test_select_ties_and_degenerate_inputs(D, oracle, dev):
     O = oracle
     anchors = D.anchors.retinanet_prior_boxes([16, 8, 4, 2, 1])     # 3069 anchors
