@@ -88,6 +88,21 @@ int detbox_assign_anchor(int mode, const float *anchors, int64_t P,
                          float *target_locs, int64_t *target_labels, int64_t *matched,
                          int64_t *best_anchor, void *workspace, size_t workspace_bytes, void *stream);
 
+/* detbox_assign_anchor for callers that cannot allocate device memory or bring a workspace: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same
+ * arguments, results and kernels as detbox_assign_anchor, minus the workspace: the per-GT arg-max slots live in an
+ * array inside the library (8 * DETBOX_ASSIGN_NOALLOC_MAX_GT bytes = 512 KiB on every GPU the library runs on,
+ * held until the process ends).  total_gt beyond DETBOX_ASSIGN_NOALLOC_MAX_GT returns DETBOX_ERR_UNSUPPORTED.
+ * The call makes no hipMalloc / hipFree; the device that `stream` belongs to must be current.  All calls on one
+ * GPU share that GPU's array: calls that overlap there (two streams, two threads) race; order them on one
+ * stream or use detbox_assign_anchor with separate workspaces. */
+#define DETBOX_ASSIGN_NOALLOC_MAX_GT 65536
+int detbox_assign_anchor_noalloc(int mode, const float *anchors, int64_t P,
+                                 const float *gt_boxes, const int64_t *gt_labels, const int32_t *gt_offsets,
+                                 int64_t B, int64_t total_gt, float thr_lo, float thr_hi,
+                                 float *target_locs, int64_t *target_labels, int64_t *matched,
+                                 int64_t *best_anchor, void *stream);
+
 /* Replaces src/models/fcos.py:211-243.  points [P,2], regress_ranges [P,2] (inclusive both ends),
  * GT cxcywh in pixels.  target_locs [B,P,4] = rays (l,r,t,b) of the matched box, target_cents [B,P],
  * target_labels [B,P], matched [B,P].  Rows with label 0 hold the rays of GT 0 and a centerness

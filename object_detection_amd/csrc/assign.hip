@@ -19,6 +19,7 @@
 // packing (iou bits, ~anchor index) into one 64-bit key.
 #include "detbox_internal.h"
 #include <cstdlib>
+#include <mutex>
 
 using namespace detbox;
 
@@ -309,26 +310,14 @@ extern "C" size_t detbox_assign_anchor_workspace_bytes(int64_t total_gt) {
     return align_up((size_t)total_gt * sizeof(unsigned long long) + 256, 256);
 }
 
-extern "C" int detbox_assign_anchor(int mode, const float *anchors, int64_t P,
-                                    const float *gt_boxes, const int64_t *gt_labels, const int32_t *gt_offsets,
-                                    int64_t B, int64_t total_gt, float thr_lo, float thr_hi,
-                                    float *target_locs, int64_t *target_labels, int64_t *matched,
-                                    int64_t *best_anchor, void *workspace, size_t workspace_bytes, void *stream) {
-    DETBOX_CHECK_ARG(mode == DETBOX_ASSIGN_CXCYWH || mode == DETBOX_ASSIGN_YOLO, "unknown mode");
-    DETBOX_CHECK_ARG(P >= 0 && B >= 0 && total_gt >= 0, "negative size");
-    DETBOX_CHECK_ARG(P < (1ll << 31) && total_gt < (1ll << 31), "P and total_gt must fit 31 bits");
-    if (P == 0 || B == 0) return DETBOX_OK;
-    DETBOX_CHECK_ARG(anchors && gt_offsets && target_locs && target_labels && matched, "null pointer");
-    DETBOX_CHECK_ARG(total_gt == 0 || (gt_boxes && gt_labels), "null GT pointer");
-    DETBOX_CHECK_ARG((uintptr_t)target_locs % 16 == 0 && (uintptr_t)gt_boxes % 16 == 0, "float4 arrays must be 16-byte aligned");
-    DETBOX_CHECK_ARG(mode != DETBOX_ASSIGN_CXCYWH || (uintptr_t)anchors % 16 == 0, "anchors must be 16-byte aligned");
-    if (workspace_bytes < detbox_assign_anchor_workspace_bytes(total_gt) || !workspace || (uintptr_t)workspace % 256) {
-        set_error("detbox_assign_anchor: workspace missing, misaligned or smaller than %zu bytes",
-                  detbox_assign_anchor_workspace_bytes(total_gt));
-        return DETBOX_ERR_WORKSPACE;
-    }
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    unsigned long long *colbest = static_cast<unsigned long long *>(workspace);
+namespace {
+
+// Shared by the two entry points: `colbest` holds one 64-bit slot per GT box (cleared here, on the stream).
+int assign_anchor_run(int mode, const float *anchors, int64_t P,
+                      const float *gt_boxes, const int64_t *gt_labels, const int32_t *gt_offsets,
+                      int64_t B, int64_t total_gt, float thr_lo, float thr_hi,
+                      float *target_locs, int64_t *target_labels, int64_t *matched,
+                      int64_t *best_anchor, unsigned long long *colbest, hipStream_t s) {
     if (total_gt > 0) DETBOX_HIP(hipMemsetAsync(colbest, 0, (size_t)total_gt * sizeof(unsigned long long), s));
     // four anchors per thread once that still leaves about four workgroups per CU (33 against 44 us on 16 x 120087 anchors)
     const int apt = (P * B >= (int64_t)4 * ASSIGN_BLOCK * 1024) ? 4 : 1;
@@ -354,6 +343,90 @@ extern "C" int detbox_assign_anchor(int mode, const float *anchors, int64_t P,
         DETBOX_LAUNCH_CHECK();
     }
     return DETBOX_OK;
+}
+
+int assign_anchor_check(int mode, const float *anchors, int64_t P, const float *gt_boxes, const int64_t *gt_labels,
+                        const int32_t *gt_offsets, int64_t B, int64_t total_gt, const float *target_locs,
+                        const int64_t *target_labels, const int64_t *matched) {
+    DETBOX_CHECK_ARG(mode == DETBOX_ASSIGN_CXCYWH || mode == DETBOX_ASSIGN_YOLO, "unknown mode");
+    DETBOX_CHECK_ARG(P >= 0 && B >= 0 && total_gt >= 0, "negative size");
+    DETBOX_CHECK_ARG(P < (1ll << 31) && total_gt < (1ll << 31), "P and total_gt must fit 31 bits");
+    if (P == 0 || B == 0) return DETBOX_OK;
+    DETBOX_CHECK_ARG(anchors && gt_offsets && target_locs && target_labels && matched, "null pointer");
+    DETBOX_CHECK_ARG(total_gt == 0 || (gt_boxes && gt_labels), "null GT pointer");
+    DETBOX_CHECK_ARG((uintptr_t)target_locs % 16 == 0 && (uintptr_t)gt_boxes % 16 == 0, "float4 arrays must be 16-byte aligned");
+    DETBOX_CHECK_ARG(mode != DETBOX_ASSIGN_CXCYWH || (uintptr_t)anchors % 16 == 0, "anchors must be 16-byte aligned");
+    return DETBOX_OK;
+}
+
+}  // namespace
+
+extern "C" int detbox_assign_anchor(int mode, const float *anchors, int64_t P,
+                                    const float *gt_boxes, const int64_t *gt_labels, const int32_t *gt_offsets,
+                                    int64_t B, int64_t total_gt, float thr_lo, float thr_hi,
+                                    float *target_locs, int64_t *target_labels, int64_t *matched,
+                                    int64_t *best_anchor, void *workspace, size_t workspace_bytes, void *stream) {
+    if (int rc = assign_anchor_check(mode, anchors, P, gt_boxes, gt_labels, gt_offsets, B, total_gt, target_locs,
+                                     target_labels, matched)) return rc;
+    if (P == 0 || B == 0) return DETBOX_OK;
+    if (workspace_bytes < detbox_assign_anchor_workspace_bytes(total_gt) || !workspace || (uintptr_t)workspace % 256) {
+        set_error("detbox_assign_anchor: workspace missing, misaligned or smaller than %zu bytes",
+                  detbox_assign_anchor_workspace_bytes(total_gt));
+        return DETBOX_ERR_WORKSPACE;
+    }
+    return assign_anchor_run(mode, anchors, P, gt_boxes, gt_labels, gt_offsets, B, total_gt, thr_lo, thr_hi, target_locs,
+                             target_labels, matched, best_anchor, static_cast<unsigned long long *>(workspace),
+                             static_cast<hipStream_t>(stream));
+}
+
+// ---- the same assignment for callers that cannot allocate -------------------------------------------------
+// The per-GT arg-max slots live in a device array of this library instead of a caller workspace.  Every GPU the
+// library runs on holds its own copy at its own address; the address is looked up once per device (with that
+// device current) and kept.  Host code only ever uses that looked-up pointer.
+static __device__ __align__(256) unsigned long long scratch[DETBOX_ASSIGN_NOALLOC_MAX_GT];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+unsigned long long *g_scratch_ptr[MAX_DEVICES];       // per device: where `scratch` lives there
+
+int scratch_of_current_device(unsigned long long **out) {
+    int dev = -1;
+    DETBOX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) {
+        set_error("detbox_assign_anchor_noalloc: device ordinal %d beyond the %d this entry point keeps track of", dev, MAX_DEVICES);
+        return DETBOX_ERR_UNSUPPORTED;
+    }
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        DETBOX_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) { set_error("detbox_assign_anchor_noalloc: no address for the scratch array on device %d", dev); return DETBOX_ERR_HIP; }
+        g_scratch_ptr[dev] = static_cast<unsigned long long *>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return DETBOX_OK;
+}
+}  // namespace
+
+extern "C" int detbox_assign_anchor_noalloc(int mode, const float *anchors, int64_t P,
+                                            const float *gt_boxes, const int64_t *gt_labels, const int32_t *gt_offsets,
+                                            int64_t B, int64_t total_gt, float thr_lo, float thr_hi,
+                                            float *target_locs, int64_t *target_labels, int64_t *matched,
+                                            int64_t *best_anchor, void *stream) {
+    if (int rc = assign_anchor_check(mode, anchors, P, gt_boxes, gt_labels, gt_offsets, B, total_gt, target_locs,
+                                     target_labels, matched)) return rc;
+    if (total_gt > DETBOX_ASSIGN_NOALLOC_MAX_GT) {
+        set_error("detbox_assign_anchor_noalloc: %lld ground-truth boxes in the batch, the built-in scratch holds %d; "
+                  "use detbox_assign_anchor with a workspace", (long long)total_gt, DETBOX_ASSIGN_NOALLOC_MAX_GT);
+        return DETBOX_ERR_UNSUPPORTED;
+    }
+    if (P == 0 || B == 0) return DETBOX_OK;
+    unsigned long long *colbest = nullptr;
+    if (int rc = scratch_of_current_device(&colbest)) return rc;
+    // assign_anchor_run clears the slots it uses on the stream before the kernels: the array keeps the last call's contents
+    return assign_anchor_run(mode, anchors, P, gt_boxes, gt_labels, gt_offsets, B, total_gt, thr_lo, thr_hi, target_locs,
+                             target_labels, matched, best_anchor, colbest, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int detbox_assign_fcos(const float *points, const float *regress_ranges, int64_t P,
