@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Benchmark of the detection box-ops hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--regime dense|sparse]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--regime dense|sparse|trained]
+
+With --gpus N > 1 and no RANK / WORLD_SIZE in the environment the script starts its N ranks itself (one process
+per GPU, rendezvous on 127.0.0.1) and relays rank 0's line; under torch.distributed.run it is simply one rank.
 
 One "step" = one pass of the whole path over one batch of synthetic head outputs that already sit
 in HBM: target assignment (train side) + activation + threshold/top-k/decode + per-class NMS +
@@ -59,8 +62,8 @@ def synth_gt(i, num_fg, coco_like, fmt, scale):
 
 
 def synth_head(i, P, C, family, regime):
-    """Head outputs of image i (seed 2000+i): locs ~ N(0,1), logits ~ N(0,1) (dense) or with the
-    background column +8 / objectness -6 (sparse)."""
+    """Head outputs of image i (seed 2000+i): locs ~ N(0,1), logits ~ N(0,1) (dense), with the background
+    column +8 / objectness -6 (sparse), or with a background column that dominates (trained)."""
     g = torch.Generator().manual_seed(2000 + i)
     locs = torch.randn(P, 4, generator=g)
     confs = torch.randn(P, C, generator=g)
@@ -70,6 +73,13 @@ def synth_head(i, P, C, family, regime):
             ext -= 6.0
         else:
             confs[:, 0] += 8.0
+    elif regime == 'trained':
+        # what a trained model looks like to this path: nearly every anchor is confidently background, a few
+        # hundred scores per image pass the threshold, so the threshold binds (not top-k) and NMS has little to do
+        if family == 'yolo':
+            ext -= 9.0
+        else:
+            confs[:, 0] += (10.5 if P > 50000 else 9.0)
     return locs, confs, ext
 
 
@@ -169,83 +179,93 @@ def cpu_baseline(wl, n_img):
     return n_img / dt, dt, len(res)
 
 
-def measured_traffic(args, kernel):
+def measured_traffic(workload, regime, kernel):
     """HBM bytes per launch of `kernel` from the committed counter passes (profiles/traffic.json, written
     by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command), or None."""
     try:
         with open(os.path.join(REPO, 'profiles', 'traffic.json')) as f:
             t = json.load(f)
-        return t[f'{args.workload}/{args.regime}'][kernel]['hbm_bytes_per_launch']
+        return t[f'{workload}/{regime}'][kernel]['hbm_bytes_per_launch']
     except (OSError, KeyError, ValueError):
         return None
 
 
-def main():
-    if os.environ.get('DETBOX_BENCH_DEBUG'):
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ['DETBOX_BENCH_DEBUG']), exit=True)
+KERNELS = ['assign_anchor', 'assign_fixup', 'assign_fcos', 'select_sample', 'select_plan', 'select_scan',
+           'select_bucket', 'select_check', 'select_fallback', 'select_materialize', 'score_hist', 'select_kth',
+           'select_refine', 'select_emit', 'select_finalize', 'nms_segments', 'nms_scan', 'nms_merge', 'pack_detections']
+PRICED = ('select_scan', 'score_hist', 'select_emit', 'assign_anchor', 'assign_fcos', 'nms_segments', 'select_finalize')
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--blocks', type=int, default=7,
+                    help='the timed region of exactly --steps steps is repeated this many times; value is the median block')
     ap.add_argument('--workload', default='retinanet800', choices=sorted(WORKLOADS))
-    ap.add_argument('--regime', default='dense', choices=['dense', 'sparse'])
+    ap.add_argument('--regime', default='dense', choices=['dense', 'sparse', 'trained'])
     ap.add_argument('--cpu-images', type=int, default=-1, help='images in the CPU baseline sample (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle timing (profiling runs)')
+    ap.add_argument('--no-extra', action='store_true', help='skip the `workloads` object (the other headline configurations)')
     ap.add_argument('--graph', action='store_true',
                     help='N=1 only: capture one step per stream in a HIP graph and replay it in the timed region (launch-bound workloads)')
     ap.add_argument('--streams', type=int, default=2,
                     help='steps are issued round-robin on this many HIP streams (independent batches in flight)')
-    ap.add_argument('--exchange', default='root', choices=['root', 'all'],
-                    help='N>1: detections are gathered to rank 0 (one evaluator process) or to every rank')
-    args = ap.parse_args()
+    ap.add_argument('--exchange', default='all', choices=['all', 'root'],
+                    help='N>1: every rank receives the detections of all ranks (all-gather), or only rank 0 does (gather)')
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and rank == 0:
-        print(f'[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE', file=sys.stderr)
-    # DETBOX_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
-    backend = os.environ.get('DETBOX_BENCH_BACKEND', 'nccl')
-    local_dev = local_rank % max(torch.cuda.device_count(), 1) if backend != 'nccl' else local_rank
-    torch.cuda.set_device(local_dev)
-    dev = torch.device('cuda', local_dev)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
 
-    wl = Workload(args.workload, args.regime, rank, dev)
-    wl.exchange_root = 0 if args.exchange == 'root' else None
-    B, P, C = wl.B, wl.P, wl.C
+def spawn_ranks(args, argv):
+    """--gpus N without a launcher: this process starts the N ranks (fresh interpreters of this script, one per
+    GPU), relays rank 0's JSON line and fails if any rank fails.  Nothing here touches the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    out, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f'[bench] ranks failed (rank, exit code): {bad}', file=sys.stderr)
+        return 1
+    return 0
+
+
+def measure(wl, args, world, dist, steps, warmup, blocks, streams_n, use_graph):
+    """Warm-up, an untimed survey pass with every kernel bracketed by events, then `blocks` timed regions of
+    exactly `steps` steps, each bracketed by barrier + synchronize, with events on the dominant kernel only."""
+    dev, B = wl.dev, wl.B
 
     def barrier():
         if world > 1:
             if wl.exchange is not None:
-                wl.exchange.finish()            # every batch's all-gather is complete before the clock is read
+                wl.exchange.finish()            # every batch's gather is complete before the clock is read
             torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
     out = None
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         out = wl.step(world)
     torch.cuda.synchronize()
-    _, c, kc, _, _, row_off = out
+    _, c, kc, _, _, _ = out
     n_cand = float(c.counts.sum().item()) / B
     n_keep = float(kc.clamp(min=0).sum().item()) / B
     if bool((kc < 0).any().item()):
         raise RuntimeError('NMS reported an error flag')
 
-    names = ['assign_anchor', 'assign_fixup', 'assign_fcos', 'select_sample', 'select_plan', 'select_scan',
-             'select_bucket', 'select_check', 'select_materialize', 'score_hist', 'select_kth', 'select_refine', 'select_emit',
-             'select_finalize', 'nms_segments', 'nms_scan', 'nms_merge', 'pack_detections']
-    priced = ('select_scan', 'score_hist', 'select_emit', 'assign_anchor', 'assign_fcos', 'nms_segments', 'select_finalize')
-
-    # Untimed survey pass: every kernel bracketed by events -> the per-kernel table and the dominant kernel.
     ops.profile_reset()
     ops.profile_only('')
     ops.profile_enable(True)
@@ -254,19 +274,18 @@ def main():
     torch.cuda.synchronize()
     ops.profile_enable(False)
     kern = {}
-    for nm in names:
+    for nm in KERNELS:
         ms, n = ops.profile_read(nm)
         if n:
             kern[nm] = dict(total_ms=ms, launches=n, avg_us=1e3 * ms / n)
-    dom = max((k for k in kern if k in priced), key=lambda k: kern[k]['total_ms'])
+    dom = max((k for k in kern if k in PRICED), key=lambda k: kern[k]['total_ms'])
 
-    # Timed region: only the dominant kernel carries events, on the stream it is launched on.
     ops.profile_reset()
     ops.profile_only(dom)
     ops.profile_enable(True)
     graph = None
-    streams = StreamRing(dev, args.streams) if args.streams > 1 else None
-    if args.graph and world == 1:
+    streams = StreamRing(dev, streams_n) if streams_n > 1 else None
+    if use_graph and world == 1:
         # every launch of a step goes into one HIP graph per stream (buffers come from the capture's private
         # pool, workspaces are per stream); a replay runs exactly the same kernels on the same inputs
         ops.profile_enable(False)
@@ -289,60 +308,131 @@ def main():
             with streams.next():
                 wl.step(world)
         torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if graph is not None:
-            g_, st, _ = graph[i % len(graph)]
-            with torch.cuda.stream(st):
-                g_.replay()
-        elif streams is not None:
-            with streams.next():
+    times = []
+    for _ in range(max(blocks, 1)):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if graph is not None:
+                g_, st, _ = graph[i % len(graph)]
+                with torch.cuda.stream(st):
+                    g_.replay()
+            elif streams is not None:
+                with streams.next():
+                    wl.step(world)
+            else:
                 wl.step(world)
-        else:
-            wl.step(world)
-    barrier()
-    elapsed = time.perf_counter() - t0
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        times.append(elapsed)
     ops.profile_enable(False)
     ops.profile_only('')
+    ms, n = ops.profile_read(dom)
+    if n == 0:                                   # graph replay: no events inside; the survey pass stands in
+        ms, n = kern[dom]['total_ms'], kern[dom]['launches']
+    launch = (f'hip-graph replay on {len(graph)} stream(s)' if graph is not None
+              else ('stream' if streams is None else f'{len(streams)} streams, steps round-robin'))
+    return dict(times=times, kern=kern, dom=dom, dom_us=1e3 * ms / max(n, 1), dom_launches=n, n_cand=n_cand, n_keep=n_keep,
+                launch=launch, streams=(1 if streams is None else len(streams)))
+
+
+def price(wl, m, world, steps):
+    """Throughput and roofline figures of one measured workload."""
+    B, P, C = wl.B, wl.P, wl.C
+    n_cand, n_keep, kern, dom = m['n_cand'], m['n_keep'], m['kern'], m['dom']
+    G_mean = wl.total_gt / B
+    score_bytes = 4.0 * B * P * C
+    alg_bytes = {      # algorithmic bytes per launch (whole batch of this rank)
+        'select_scan': score_bytes, 'score_hist': score_bytes, 'select_emit': score_bytes,
+        'assign_anchor': B * (48.0 * P + 24.0 * G_mean), 'assign_fcos': B * (52.0 * P + 24.0 * G_mean),
+        'nms_segments': B * (28.0 * n_cand + 8.0 * n_keep),
+        'select_finalize': B * (28.0 * n_cand + 32.0 * n_cand),
+    }
+    achieved = alg_bytes[dom] / (m['dom_us'] * 1e-6) / 1e9
+    roofline = dict(kernel=dom, bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
+                    frac=achieved / HBM_PEAK_GBS, traffic=measured_traffic(wl.name, wl.regime, dom), avg_us=m['dom_us'],
+                    launches=m['dom_launches'], algorithmic_bytes=alg_bytes[dom],
+                    avg_us_one_batch_in_flight=kern[dom]['avg_us'],
+                    note='avg_us is measured in the timed region, where the kernel shares the CUs with the other '
+                         'batch in flight; avg_us_one_batch_in_flight comes from the single-stream survey pass')
+    if dom == 'nms_segments':
+        # greedy NMS is O(n * kept) pair tests on data that stays on chip: VALU issue, not HBM, is what it can
+        # saturate.  valu_frac = VALU wave-instructions x 4 cycles / (SIMDs x kernel cycles), from the committed
+        # counter pass of this command (profiles/), scaled to the duration measured here.
+        v = measured_valu(wl.name, wl.regime)
+        if v is not None:
+            roofline['valu_frac'] = v['valu_insts_per_launch'] * 4.0 / (v['simds'] * v['clock_mhz'] * m['dom_us'])
+            roofline['valu_insts_per_launch'] = v['valu_insts_per_launch']
+    streaming = None
+    if 'select_scan' in kern:
+        a = score_bytes / (kern['select_scan']['avg_us'] * 1e-6) / 1e9
+        streaming = dict(kernel='select_scan', bound='hbm', achieved=a, peak=HBM_PEAK_GBS, unit='GB/s',
+                         frac=a / HBM_PEAK_GBS, traffic=measured_traffic(wl.name, wl.regime, 'select_scan'),
+                         avg_us=kern['select_scan']['avg_us'], algorithmic_bytes=score_bytes,
+                         note='survey pass: every kernel bracketed by events')
+    anchor_bytes = {'fcos': 8, 'yolo': 20}.get(wl.w['family'], 16)
+    bytes_img = ((52.0 if wl.w['family'] == 'fcos' else 48.0) * P + 24.0 * G_mean
+                 + 4.0 * P * C + 16.0 * P + anchor_bytes * P + (4.0 * P if wl.ext is not None else 0.0) + 28.0 * n_cand
+                 + 28.0 * n_cand + 8.0 * n_keep)
+    ts = sorted(m['times'])
+    med = ts[len(ts) // 2]
+    ips = world * B * steps / med
+    return dict(ips=ips, ms_per_step=1e3 * med / steps, roofline=roofline, streaming=streaming, bytes_img=bytes_img,
+                hbm_frac=bytes_img * ips / world / (HBM_PEAK_GBS * 1e9),
+                blocks=dict(n=len(ts), steps_each=steps, ms_per_step_min=1e3 * ts[0] / steps, ms_per_step_median=1e3 * med / steps,
+                            ms_per_step_max=1e3 * ts[-1] / steps),
+                sub30_us_total=sum(v['avg_us'] for v in kern.values() if v['avg_us'] < 30.0),
+                launches_per_step=sum(v['launches'] for v in kern.values()) / 5.0)
+
+
+def measured_valu(workload, regime):
+    try:
+        with open(os.path.join(REPO, 'profiles', 'valu.json')) as f:
+            return json.load(f)[f'{workload}/{regime}']['nms_segments']
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def main():
+    if os.environ.get('DETBOX_BENCH_DEBUG'):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['DETBOX_BENCH_DEBUG']), exit=True)
+    args = parse_args()
+    if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))      # before anything initialises the GPU in this process
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and rank == 0:
+        print(f'[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE', file=sys.stderr)
+    # DETBOX_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    backend = os.environ.get('DETBOX_BENCH_BACKEND', 'nccl')
+    local_dev = local_rank % max(torch.cuda.device_count(), 1) if backend != 'nccl' else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device('cuda', local_dev)
+    dist = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    wl = Workload(args.workload, args.regime, rank, dev)
+    wl.exchange_root = 0 if args.exchange == 'root' else None
+    B, P, C = wl.B, wl.P, wl.C
+    m = measure(wl, args, world, dist, args.steps, args.warmup, args.blocks, args.streams, args.graph)
+    host_waits = wl.exchange.host_waits if wl.exchange is not None else None
+    gt_mean = wl.total_gt / B
 
     if rank == 0:
-        ms, n = ops.profile_read(dom)
-        if n == 0:                                   # graph replay: no events inside; fall back to the survey pass
-            ms, n = kern[dom]['total_ms'], kern[dom]['launches']
-        dom_us = 1e3 * ms / max(n, 1)
-        G_mean = wl.total_gt / B
-        score_bytes = 4.0 * B * P * C
-        alg_bytes = {      # algorithmic bytes per launch (whole batch of this rank)
-            'select_scan': score_bytes, 'score_hist': score_bytes, 'select_emit': score_bytes,
-            'assign_anchor': B * (48.0 * P + 24.0 * G_mean), 'assign_fcos': B * (52.0 * P + 24.0 * G_mean),
-            'nms_segments': B * (28.0 * n_cand + 8.0 * n_keep),
-            'select_finalize': B * (28.0 * n_cand + 32.0 * n_cand),
-        }
-        achieved = alg_bytes[dom] / (dom_us * 1e-6) / 1e9
-        roofline = dict(kernel=dom, bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=achieved / HBM_PEAK_GBS, traffic=measured_traffic(args, dom), avg_us=dom_us,
-                        launches=n, algorithmic_bytes=alg_bytes[dom],
-                        avg_us_one_batch_in_flight=kern[dom]['avg_us'],
-                        note='avg_us is measured in the timed region, where the kernel shares the CUs with the other '
-                             'batch in flight; avg_us_one_batch_in_flight comes from the single-stream survey pass')
-        # the streaming kernel of the path (reads the logits once), from the survey pass
-        streaming = None
-        if 'select_scan' in kern:
-            a = score_bytes / (kern['select_scan']['avg_us'] * 1e-6) / 1e9
-            streaming = dict(kernel='select_scan', bound='hbm', achieved=a, peak=HBM_PEAK_GBS, unit='GB/s',
-                             frac=a / HBM_PEAK_GBS, traffic=measured_traffic(args, 'select_scan'),
-                             avg_us=kern['select_scan']['avg_us'], algorithmic_bytes=score_bytes,
-                             note='survey pass: every kernel bracketed by events')
-        anchor_bytes = {'fcos': 8, 'yolo': 20}.get(wl.w['family'], 16)
-        bytes_img = ((52.0 if wl.w['family'] == 'fcos' else 48.0) * P + 24.0 * G_mean
-                     + 4.0 * P * C + 16.0 * P + anchor_bytes * P + (4.0 * P if wl.ext is not None else 0.0) + 28.0 * n_cand
-                     + 28.0 * n_cand + 8.0 * n_keep)
-        ips = world * B * args.steps / elapsed
+        pr = price(wl, m, world, args.steps)
         n_cpu = args.cpu_images if args.cpu_images >= 0 else (8 if P > 50000 else wl.B)
         cpu = None
         if world == 1 and n_cpu > 0 and not args.no_cpu_baseline:
@@ -351,20 +441,47 @@ def main():
             cpu = dict(value=v, unit='images/s', cores=torch.get_num_threads(), kind='port',
                        sample=f'{n_cpu} image(s) of the same workload through the CPU oracle '
                               f'(assign + loop-faithful pre_predict + greedy NMS + dict loop), {dt:.1f} s, {nres} detections')
+        # the other configurations the metric is quoted on, and the regime the HBM roofline was chosen for
+        extra = None
+        if world == 1 and not args.no_extra:
+            extra = {}
+            del wl
+            torch.cuda.empty_cache()
+            for name, regime, steps, graph in (('ssd300', 'dense', 200, True), ('ssd300_b512', 'dense', 20, False),
+                                               ('retinanet800', 'trained', 50, False), ('ssd300_b512', 'trained', 50, False)):
+                if name == args.workload and regime == args.regime:
+                    continue
+                w2 = Workload(name, regime, 0, dev)
+                m2 = measure(w2, args, 1, None, steps, 3, 5, args.streams, graph)
+                p2 = price(w2, m2, 1, steps)
+                extra[f'{name}/{regime}'] = {
+                    'images_per_s': p2['ips'], 'ms_per_step': p2['ms_per_step'], 'images_per_gpu': w2.B,
+                    'hbm_frac_whole_step': p2['hbm_frac'], 'algorithmic_bytes_per_image': p2['bytes_img'],
+                    'candidates_per_image': m2['n_cand'], 'kept_per_image': m2['n_keep'], 'launch': m2['launch'],
+                    'dominant_kernel': m2['dom'], 'dominant_avg_us': round(m2['kern'][m2['dom']]['avg_us'], 2),
+                    'dominant_hbm_frac': p2['roofline']['frac'], 'blocks': p2['blocks'],
+                    'kernels_avg_us': {k: round(v['avg_us'], 2) for k, v in m2['kern'].items()}}
+                del w2
+                torch.cuda.empty_cache()
         line = {
-            'metric': 'images/sec assign+decode+NMS', 'value': ips, 'unit': 'images/s', 'n_gpus': world,
-            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'metric': 'images/sec assign+decode+NMS', 'value': pr['ips'], 'unit': 'images/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': pr['ms_per_step'],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'launch': (f'hip-graph replay on {len(graph)} stream(s)' if graph is not None else ('stream' if streams is None else f'{len(streams)} streams, steps round-robin')),
-            'config': {'workload': f'{args.workload} {args.regime}: B={B}/GPU P={P} C={C} top_k={wl.top_k} conf>0.01 nms=0.45',
-                       'images_per_gpu': B, 'global_batch': world * B, 'candidates_per_image': n_cand,
-                       'kept_per_image': n_keep, 'gt_per_image': G_mean, 'parallelism': f'image-sharded x{world}', 'streams': (1 if streams is None else len(streams)), 'exchange': ('none' if world == 1 else ('gather to rank 0' if args.exchange == 'root' else 'all-gather'))},
-            'roofline': roofline,
-            'roofline_streaming': streaming,
+            'launch': m['launch'],
+            'config': {'workload': f'{args.workload} {args.regime}: B={B}/GPU P={P} C={C} top_k={WORKLOADS[args.workload]["top_k"]} conf>0.01 nms=0.45',
+                       'images_per_gpu': B, 'global_batch': world * B, 'candidates_per_image': m['n_cand'],
+                       'kept_per_image': m['n_keep'], 'gt_per_image': gt_mean, 'parallelism': f'image-sharded x{world}',
+                       'streams': m['streams'],
+                       'exchange': ('none' if world == 1 else ('gather to rank 0' if args.exchange == 'root' else 'all-gather')),
+                       'exchange_host_waits': host_waits},
+            'blocks': pr['blocks'],
+            'roofline': pr['roofline'],
+            'roofline_streaming': pr['streaming'],
             'cpu_baseline': cpu,
-            'pipeline': {'algorithmic_bytes_per_image': bytes_img,
-                         'hbm_frac_whole_step': bytes_img * ips / world / (HBM_PEAK_GBS * 1e9)},
-            'kernels_avg_us': {k: round(v['avg_us'], 2) for k, v in kern.items()},
+            'pipeline': {'algorithmic_bytes_per_image': pr['bytes_img'], 'hbm_frac_whole_step': pr['hbm_frac'],
+                         'launches_per_step': pr['launches_per_step'], 'sub30_us_kernels_total_us': round(pr['sub30_us_total'], 1)},
+            'kernels_avg_us': {k: round(v['avg_us'], 2) for k, v in m['kern'].items()},
+            'workloads': extra,
         }
         print(json.dumps(line))
     if world > 1:

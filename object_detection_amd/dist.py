@@ -76,19 +76,24 @@ def unpack_wire(msg: torch.Tensor, header_rows: int) -> Tuple[torch.Tensor, torc
 
 
 class RowExchange:
-    """All-gather of every batch's detections, one batch behind the computation.
+    """All-gather of every batch's detections, behind the computation and without host stalls.
 
-    submit(wire, images_cap) hands over this rank's message for the batch just launched (its row count is
-    still being computed on the device); the gather of the PREVIOUS batch is started at that moment, on a
-    side stream, so its transfer overlaps the kernels of the current batch and the host never waits for
-    the batch in flight.  finish() starts the last gather and waits for all of them.  Two collectives per
-    batch: the counts (to agree on the padded length) and the messages.  Works on gloo/CPU tensors too
-    (no streams there).
+    submit(wire, images_cap, header_rows) hands over this rank's message for the batch just launched (its row
+    count is still being computed on the device).  Each call issues, on a side stream, in the same order on
+    every rank:
+      1. the gather of the messages of the batch submitted two calls ago, sized by the row counts that were
+         exchanged one call ago and have long since arrived in pinned host memory;
+      2. the exchange of the row counts of the batch just submitted -- its input is the count word of the
+         message itself, still on the device, so the host does not need to know it; the result is copied to
+         pinned memory behind it.
+    The host therefore never waits for a collective it has just issued, only (and normally not at all) for one
+    issued a whole batch earlier; the transfers overlap the kernels of the following batches.  finish() drains
+    the pipeline and waits for every gather.  Works on gloo / CPU tensors too (no streams there; messages on a
+    GPU are staged through the host for a backend that cannot move device memory).
 
-    root=None: every rank receives every message (all-gather).  root=r: only global rank r receives them
-    (gather) -- what a single evaluator process needs (src/test.py:98-99 builds one list in one process);
-    the other ranks only send, so the traffic per batch is one message per link instead of world of them.
-    On those ranks the gathered buffer of a batch is None."""
+    root=None: every rank receives every message (all-gather: the path's one collective).  root=r: only global
+    rank r receives them (gather) -- enough for a single evaluator process (src/test.py:98-99 builds one list in
+    one process).  The mode is fixed at construction; a backend that lacks the collective raises."""
 
     def __init__(self, group=None, keep_results: bool = True, root=None):
         self.group = group
@@ -98,81 +103,88 @@ class RowExchange:
         # RCCL moves device buffers; any other backend (gloo rehearsals) gets the message staged on the host
         self.device_collectives = self.world > 1 and dist.get_backend(group) == 'nccl'
         self.keep_results = keep_results
-        self.waiting = []        # submitted, gather not started: (wire, header_rows, event, pinned count)
-        self.flying = []         # gathers started: (work, out, header_rows, counts)
-        self.results = []        # per batch: (out [world, rows, 6], header_rows, counts)
+        self.counted = []        # counts exchange issued: (wire, header_rows, counts_host, counts_event, counts_work)
+        self.flying = []         # message gathers issued: (work, out, header_rows, counts, send)
+        self.results = []        # per batch: (out [world, rows, 6] or list of world [rows, 6], header_rows, counts)
         self.comm = None
-        self.pins, self.pin_next = [], 0
+        self.host_waits = 0      # times the host found a counts exchange of an earlier batch still unfinished
 
-    def submit(self, wire: torch.Tensor, images_cap: int, header_rows: int):
-        ev = pin = None
-        if wire.is_cuda:
+    # -- stage 2: the row counts of the batch just submitted
+    def _issue_counts(self, wire: torch.Tensor, header_rows: int):
+        word = wire.reshape(-1)[:1]
+        if self.world == 1:
+            if wire.is_cuda:
+                host = torch.empty(1, dtype=torch.int32).pin_memory()
+                host.copy_(word, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(wire.device))
+                return (wire, header_rows, host, ev, None)
+            return (wire, header_rows, word.clone(), None, None)
+        if wire.is_cuda and self.device_collectives:
             if self.comm is None:
                 self.comm = torch.cuda.Stream(wire.device)
-            if not self.pins:
-                self.pins = [torch.empty(1, dtype=torch.int32).pin_memory() for _ in range(4)]
-            pin = self.pins[self.pin_next % 4]       # at most two batches wait at any time
-            self.pin_next += 1
-            pin.copy_(wire.reshape(-1)[:1], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(wire.device))
-        item = (wire, header_rows, ev, pin)
-        if self.waiting:
-            self._start(self.waiting.pop(0))
-        self.waiting.append(item)
+            self.comm.wait_stream(torch.cuda.current_stream(wire.device))      # the message is being written there
+            with torch.cuda.stream(self.comm):
+                counts = torch.empty(self.world, dtype=torch.int32, device=wire.device)
+                dist.all_gather_into_tensor(counts, word, group=self.group)    # enqueued on the side stream
+                host = torch.empty(self.world, dtype=torch.int32).pin_memory()
+                host.copy_(counts, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.comm)
+                wire.record_stream(self.comm)
+            return (wire, header_rows, host, ev, None)
+        # host-staged backends: the count has to come down first (a rehearsal path, not the product path)
+        n = torch.tensor([int(word.item())], dtype=torch.int32)
+        host = torch.empty(self.world, dtype=torch.int32)
+        work = dist.all_gather_into_tensor(host, n, group=self.group, async_op=True)
+        return (wire, header_rows, host, None, work)
 
-    def _start(self, item):
-        wire, header_rows, ev, pin = item
+    # -- stage 1: the messages of a batch whose counts have arrived
+    def _issue_messages(self, item):
+        wire, header_rows, host, ev, cwork = item
+        if cwork is not None:
+            cwork.wait()
+        if ev is not None:
+            if not ev.query():
+                self.host_waits += 1
+            ev.synchronize()
+        counts = [int(c) for c in host.tolist()]
         if self.world == 1:
-            n = int(wire.reshape(-1)[0]) if ev is None else None
-            if ev is not None:
-                ev.synchronize()
-                n = int(pin[0])
-            self.flying.append((None, wire[:header_rows + n].unsqueeze(0), header_rows, [n]))
+            self.flying.append((None, wire[:header_rows + counts[0]].unsqueeze(0), header_rows, counts, None))
             return
         import contextlib
-        if ev is not None:
-            ev.synchronize()                       # the batch whose rows these are finished long ago
-            n = int(pin[0])
-        else:
-            n = int(wire.reshape(-1)[0])
-        if wire.is_cuda and self.device_collectives:
-            ctx = torch.cuda.stream(self.comm)
-            self.comm.wait_event(ev)
-        else:
-            ctx = contextlib.nullcontext()
-            if wire.is_cuda:
-                wire = wire[:header_rows + n].cpu()
+        n = counts[self.rank]
+        rows = header_rows + max(max(counts), 0)
+        on_device = wire.is_cuda and self.device_collectives
+        ctx = torch.cuda.stream(self.comm) if on_device else contextlib.nullcontext()
         with ctx:
-            mine = torch.tensor([n], dtype=torch.int64, device=wire.device)
-            counts = torch.empty(self.world, dtype=torch.int64, device=wire.device)
-            dist.all_gather_into_tensor(counts, mine, group=self.group)
-            counts = [int(c) for c in counts.tolist()]
-            rows = header_rows + max(max(counts), 0)
+            if wire.is_cuda and not on_device:
+                wire = wire[:header_rows + n].cpu()
             if wire.shape[0] >= rows:
-                send = wire[:rows]                 # rows beyond n are padding
+                send = wire[:rows]
+                send[header_rows + n:].zero_()        # padding up to the longest message
             else:                                  # another rank has more rows than this buffer holds
                 send = torch.zeros((rows, 6), dtype=torch.int32, device=wire.device)
-                send[:wire.shape[0]] = wire
-            work = None
+                send[:header_rows + n] = wire[:header_rows + n]
+            send = send.contiguous()
             if self.root is not None:
-                send = send.contiguous()
-                out = parts = None
-                if self.rank == self.root:             # one buffer per sender, as dist.gather is most commonly given
-                    out = parts = [torch.empty((rows, 6), dtype=torch.int32, device=wire.device) for _ in range(self.world)]
-                try:
-                    work = dist.gather(send, parts, dst=self.root, group=self.group, async_op=True)
-                except (RuntimeError, NotImplementedError, ValueError):
-                    # a backend without gather refuses on every rank alike: deliver to all ranks from here on
-                    self.root = None
-            if self.root is None:
-                out = torch.empty((self.world, rows, 6), dtype=torch.int32, device=wire.device)
+                out = None
+                if self.rank == self.root:
+                    out = [torch.empty((rows, 6), dtype=torch.int32, device=send.device) for _ in range(self.world)]
+                work = dist.gather(send, out, dst=self.root, group=self.group, async_op=True)
+            else:
+                out = torch.empty((self.world, rows, 6), dtype=torch.int32, device=send.device)
                 work = dist.all_gather_into_tensor(out.view(self.world * rows, 6), send, group=self.group, async_op=True)
-            if wire.is_cuda:
+            if on_device:
                 wire.record_stream(self.comm)
         self.flying.append((work, out, header_rows, counts, send))
         while len(self.flying) > 2:                # retire old gathers (they finished long ago)
             self._retire(self.flying.pop(0))
+
+    def submit(self, wire: torch.Tensor, images_cap: int, header_rows: int):
+        if len(self.counted) >= 2:
+            self._issue_messages(self.counted.pop(0))
+        self.counted.append(self._issue_counts(wire, header_rows))
 
     def _retire(self, f):
         work, out, header_rows, counts = f[:4]
@@ -182,9 +194,9 @@ class RowExchange:
             self.results.append((out, header_rows, counts))
 
     def finish(self):
-        """Starts what is left, waits for every gather; returns the gathered messages per batch."""
-        while self.waiting:
-            self._start(self.waiting.pop(0))
+        """Drains the pipeline, waits for every gather; returns the gathered messages per batch."""
+        while self.counted:
+            self._issue_messages(self.counted.pop(0))
         for f in self.flying:
             self._retire(f)
         self.flying = []

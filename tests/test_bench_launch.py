@@ -1,0 +1,58 @@
+"""bench.py --gpus N starts its own ranks when no launcher did: checked without a GPU by running only the
+parent's part (argument parsing + rank spawning) against a stand-in child."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_parent(tmp_path, child_body, n=3):
+    """Runs bench.spawn_ranks with this file standing in for the child script."""
+    child = tmp_path / 'child.py'
+    child.write_text(textwrap.dedent(child_body))
+    driver = tmp_path / 'driver.py'
+    driver.write_text(textwrap.dedent(f'''
+        import sys
+        sys.path.insert(0, {REPO!r})
+        import bench
+        bench.__file__ = {str(child)!r}
+        args = bench.parse_args(['--gpus', '{n}', '--steps', '2'])
+        sys.exit(bench.spawn_ranks(args, ['--gpus', '{n}', '--steps', '2']))
+    '''))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    return subprocess.run([sys.executable, str(driver)], capture_output=True, text=True, env=env, timeout=300)
+
+
+def test_parent_spawns_ranks_and_relays_rank0_line(tmp_path):
+    r = _run_parent(tmp_path, '''
+        import json, os, sys
+        rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+        assert os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0
+        assert int(os.environ['LOCAL_RANK']) == rank and sys.argv[1:] == ['--gpus', str(world), '--steps', '2']
+        if rank == 0:
+            print(json.dumps({'n_gpus': world, 'rank': rank}))
+        else:
+            print('noise from rank', rank)          # must not reach the parent's stdout
+    ''')
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {'n_gpus': 3, 'rank': 0}
+
+
+def test_parent_fails_when_a_rank_fails(tmp_path):
+    r = _run_parent(tmp_path, '''
+        import os, sys
+        sys.exit(3 if os.environ['RANK'] == '1' else 0)
+    ''', n=2)
+    assert r.returncode != 0 and 'ranks failed' in r.stderr
+
+
+def test_launcher_environment_means_no_spawn():
+    """Under torch.distributed.run (RANK / WORLD_SIZE set) the script is one rank; the check is the first thing main() does."""
+    src = open(os.path.join(REPO, 'bench.py')).read()
+    main = src[src.index('def main():'):]
+    assert main.index('spawn_ranks(') < main.index('torch.cuda.set_device')
+    assert "'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ" in main

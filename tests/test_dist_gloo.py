@@ -81,6 +81,14 @@ def _fake_dets(image_index: int):
     return (torch.randint(1, 81, (n,), generator=g), torch.rand(n, 4, generator=g), torch.rand(n, generator=g))
 
 
+def _images_of(k, rank, world, per_rank):
+    """Images of `rank` in batch k: rank 1 is one image short in batch 1; in a world of four, rank 2 has none in batch 0."""
+    n = per_rank - (1 if (rank == 1 and k == 1) else 0)
+    if world >= 4 and rank == 2 and k == 0:
+        n = 0
+    return [k * world * per_rank + rank * per_rank + i for i in range(n)]
+
+
 def _exchange_worker(rank, world, port, batches, per_rank, q, root=None):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -91,7 +99,7 @@ def _exchange_worker(rank, world, port, batches, per_rank, q, root=None):
     hdr = (2 + (per_rank + 1) + 4 * per_rank + 5) // 6
     ex = RowExchange(root=root)
     for k in range(batches):
-        imgs = [k * world * per_rank + rank * per_rank + i for i in range(per_rank - (1 if (rank == 1 and k == 1) else 0))]
+        imgs = _images_of(k, rank, world, per_rank)
         dets = [_fake_dets(i) for i in imgs]
         wire = wire_from_rows(dets, [(1 << 33) + i for i in imgs], [(100 + i, 200 + i) for i in imgs], hdr)
         ex.submit(wire, per_rank, hdr)
@@ -101,12 +109,12 @@ def _exchange_worker(rank, world, port, batches, per_rank, q, root=None):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('root', [None, 1])
-def test_row_exchange_pipelined_world2(root):
+@pytest.mark.parametrize('world,root', [(2, None), (2, 1), (4, None), (4, 3)])
+def test_row_exchange_pipelined(world, root):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from helpers import rows_from_detections
-    world, batches, per_rank = 2, 3, 3
+    batches, per_rank = 5, 3
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
@@ -125,8 +133,7 @@ def test_row_exchange_pipelined_world2(root):
         for k, (gids, gvals) in enumerate(per_batch):
             imgs = []
             for rank in range(world):
-                imgs += [k * world * per_rank + rank * per_rank + i
-                         for i in range(per_rank - (1 if (rank == 1 and k == 1) else 0))]
+                imgs += _images_of(k, rank, world, per_rank)
             want_ids, want_vals = rows_from_detections([_fake_dets(i) for i in imgs], [(1 << 33) + i for i in imgs],
                                                        [(100 + i, 200 + i) for i in imgs])
             assert torch.equal(torch.from_numpy(gids), want_ids) and torch.equal(torch.from_numpy(gvals), want_vals)
