@@ -24,6 +24,7 @@
 #include "detbox_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 using namespace detbox;
@@ -35,7 +36,7 @@ constexpr int NMS_LDS_BOXES = 4096;       // segments up to this length keep the
 constexpr int NMS_MAX_SEGMENT = 262144;   // bitmap limit for presorted segments
 
 struct NmsParams {
-    int S, max_seg, n2, in_lds, presorted, thr_neg;
+    int S, max_seg, n2, in_lds, presorted, thr_neg, stats;
     long long stride;
     float thr;
 };
@@ -389,10 +390,9 @@ __host__ __device__ inline NmsFastLds nms_fast_lds(int max_seg, int n2, int blk)
 // Five workgroups per CU (five waves per SIMD) keep a whole 80-class x 16-image launch resident in one round.
 // BLK = 256: up to 4096 boxes per segment; BLK = 64: one wave per segment (up to 256 boxes), no barriers at all.
 template <int JPT, int BLK>
-__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == 256 && JPT <= 4 ? 5 : 1))) void nms_segments_fast_kernel(
+__device__ inline void nms_chunked_body(
     const float4 *__restrict__ boxes, const float *__restrict__ scores, const int32_t *__restrict__ seg_off,
-    NmsParams np, float2 *__restrict__ kept, int32_t *__restrict__ kcount) {
-    extern __shared__ unsigned long long s_dyn[];
+    const NmsParams &np, float2 *__restrict__ kept, int32_t *__restrict__ kcount, unsigned long long *s_dyn) {
     const int s = blockIdx.x, b = blockIdx.y;
     const int32_t *so = seg_off + (size_t)b * (np.S + 1);
     const int seg0 = so[s];
@@ -669,6 +669,389 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == 256 
         const int pos = seg0 + orig[m];
         kept[row0 + rank] = make_float2(__uint_as_float(okey_from_bits(__float_as_uint(scores[(size_t)b * np.stride + pos] + 0.0f))), __int_as_float(pos));
     }
+}
+
+template <int JPT, int BLK>
+__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == 256 && JPT <= 4 ? 5 : 1))) void nms_segments_fast_kernel(
+    const float4 *__restrict__ boxes, const float *__restrict__ scores, const int32_t *__restrict__ seg_off,
+    NmsParams np, float2 *__restrict__ kept, int32_t *__restrict__ kcount) {
+    extern __shared__ unsigned long long s_dyn[];
+    nms_chunked_body<JPT, BLK>(boxes, scores, seg_off, np, kept, kcount, s_dyn);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pair-list form of the same greedy NMS (unsorted segments of at most 256*JPT boxes, JPT <= 4, threshold >= 0).
+//
+// Greedy NMS keeps box j iff no KEPT box i before it (in descending score order) has iou(i, j) > thr.  That
+// is a function of the set of edges {(i, j): i before j, iou(i, j) > thr} alone, so the kernel first finds
+// all edges -- an order-free all-pairs join with no dependency between pairs -- and only then walks them
+// in score order:
+//   1. sort (registers, as in the chunked kernel); every wave then owns JPT 64-box chunks of the sorted
+//      order, dealt boustrophedon so that the four waves (one per SIMD) carry equal shares of the triangle;
+//   2. filter: box i (broadcast from LDS) against a wave's 64-box slots with about two VALU instructions per 64
+//      pairs.  With p = |cx_i - cx_j|, q = |cy_i - cy_j|, W = (w_i + w_j) / 2, H = (h_i + h_j) / 2, the overlaps
+//      satisfy  overlap_x <= W - p,  overlap_y <= H - q,  and  iou > thr  means
+//          overlap_x * overlap_y > t * (A_i + A_j),  t = thr / (1 + thr).
+//      By AM-GM  (W - p) + (H - q) >= 2 sqrt((W - p)(H - q)) > 2 sqrt(t (A_i + A_j)) >= sqrt(2 t) (sqrt A_i + sqrt A_j),
+//      hence     p + q < r_i + r_j,   r = (w + h) / 2 - sqrt(2 t w h)   (>= 0 for thr <= 1).
+//      Centres on a 15-bit grid, radii rounded up: v_sad_u16 gives p + q + (BIAS - r_j) per slot, the minimum
+//      over the wave's slots against BIAS + r_i decides whether anything is near box i at all.  Pairs that pass
+//      (under one per thousand) are appended to the wave's own queue in LDS (no atomics: a wave-uniform count
+//      and mbcnt ranks);
+//   3. exact test: the wave drains its queue 64 pairs at a time with the reference's fp32 arithmetic
+//      (division-free where margins decide, the IEEE division in the sliver), compacting the true edges
+//      in place at the front of the queue;
+//   4. resolve: chunk by chunk in score order, edges from earlier chunks remove their targets if the
+//      source was kept, edges inside the chunk form the 64 x 64 words one wave resolves serially.
+// No barrier inside the all-pairs phase.  If a wave's queue cannot hold its edges (heavily clustered boxes:
+// many true suppressions) the segment is redone by the chunked algorithm above, whose cost shrinks exactly
+// when suppressions are many.  The results are the reference's, bit for bit: the filter only ever discards
+// pairs that cannot suppress, and every edge is decided by the exact test.
+// ---------------------------------------------------------------------------------------------
+
+constexpr uint32_t PAIR_BIAS = 1u << 24;          // radii stay below 2^17 grid units
+
+// Measurement aid (detbox_debug_nms_stats): segments, segments redone by the chunked algorithm, pairs that passed
+// the filter, true edges, queue drains -- summed over all launches since the last reset.
+__device__ unsigned long long g_pair_stats[8];
+
+struct NmsPairLds { size_t xq, irec, orig, removed, mask, misc, wprefix, total; };
+
+__host__ __device__ inline int pair_queue_cap(int blk) { return blk > 64 ? 1024 : 1024; }
+
+__host__ __device__ inline NmsPairLds nms_pair_lds(int max_seg, int n2, int blk) {
+    const size_t words_cap = (size_t)((max_seg + 63) >> 6);
+    NmsPairLds l;
+    size_t off = 0;
+    const size_t xch = blk > 64 ? (size_t)(n2 > blk ? n2 : blk) * 8 : 0;          // sort exchange buffer, dead before the queues fill
+    const size_t queues = (size_t)(blk / 64) * pair_queue_cap(blk) * 4;
+    l.xq = off;      off += xch > queues ? xch : queues;
+    l.irec = off;    off += (size_t)((max_seg + 63) & ~63) * 8 + 64;              // per box: packed centre, BIAS + radius (+ read-ahead slack)
+    l.orig = off;    off += (((size_t)max_seg * 2 + 15) & ~(size_t)15);          // sorted position -> row inside the segment
+    l.removed = off; off += ((words_cap * 8 + 15) & ~(size_t)15);
+    l.mask = off;    off += 64 * 8;
+    l.misc = off;    off += 128;                                                 // keep word; extent reduction; edge counts; overflow flag
+    l.wprefix = off; off += ((words_cap * 4 + 15) & ~(size_t)15);
+    l.total = off;
+    return l;
+}
+
+// Returns false when a queue overflowed (block-uniform): nothing was written, the caller falls back.
+template <int JPT, int BLK>
+__device__ inline bool nms_pairs_body(
+    const float4 *__restrict__ boxes, const float *__restrict__ scores, const int32_t *__restrict__ seg_off,
+    const NmsParams &np, float2 *__restrict__ kept, int32_t *__restrict__ kcount, unsigned long long *s_dyn) {
+    static_assert(JPT <= 4, "the sweep is specialised for at most four slots per wave");
+    constexpr int W = BLK / 64;
+    constexpr int QCAP = 1024;
+    const int s = blockIdx.x, b = blockIdx.y;
+    const int32_t *so = seg_off + (size_t)b * (np.S + 1);
+    const int seg0 = so[s];
+    const int n = so[s + 1] - seg0;
+    if (threadIdx.x == 0) kcount[(size_t)b * np.S + s] = 0;
+    if (n <= 0) return true;
+    if (n > np.max_seg) {
+        if (threadIdx.x == 0) kcount[(size_t)b * np.S + s] = -1;      // reported as keep_counts[b] = -1
+        return true;
+    }
+    const NmsPairLds ld = nms_pair_lds(np.max_seg, np.n2, BLK);
+    char *lds_base = reinterpret_cast<char *>(s_dyn);
+    unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(lds_base + ld.xq);
+    uint32_t *s_queue = reinterpret_cast<uint32_t *>(lds_base + ld.xq);
+    uint2 *s_irec = reinterpret_cast<uint2 *>(lds_base + ld.irec);
+    uint16_t *s_orig = reinterpret_cast<uint16_t *>(lds_base + ld.orig);
+    unsigned long long *s_removed = reinterpret_cast<unsigned long long *>(lds_base + ld.removed);
+    unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(lds_base + ld.mask);
+    float *s_red = reinterpret_cast<float *>(lds_base + ld.misc + 16);            // 4 x 4 floats
+    uint32_t *s_ne = reinterpret_cast<uint32_t *>(lds_base + ld.misc + 80);       // edges per wave
+    uint32_t *s_ovf = reinterpret_cast<uint32_t *>(lds_base + ld.misc + 96);
+    uint32_t *s_wprefix = reinterpret_cast<uint32_t *>(lds_base + ld.wprefix);
+
+    const size_t row0 = (size_t)b * np.stride + seg0;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform, and known to be
+    const int words = (n + 63) >> 6;
+    const float thr = np.thr;
+    const float k_hi = thr * 1.000001f, k_lo = thr * 0.999999f;
+    const float u_min = thr > 0.0f ? 1e-30f / thr : __builtin_inff();
+
+    // ---- 1. sort
+    int n2 = 2;
+    while (n2 < n) n2 <<= 1;
+    {
+        unsigned long long K[JPT];
+#pragma unroll
+        for (int m = 0; m < JPT; ++m) {
+            const int i = tid + m * BLK;
+            K[m] = 0ull;
+            if (i < n)   // every real key is above the zero padding: its low word is 0xffffffff - i > 0
+                K[m] = ((unsigned long long)okey_from_bits(__float_as_uint(scores[row0 + i] + 0.0f)) << 32) |
+                       (unsigned long long)(0xffffffffu - (uint32_t)i);
+        }
+        bitonic_desc_u64_regs<JPT, BLK>(K, s_keys, n2, tid);
+#pragma unroll
+        for (int m = 0; m < JPT; ++m) {
+            const int i = tid + m * BLK;
+            if (i < n) s_orig[i] = (uint16_t)(0xffffffffu - (uint32_t)(K[m] & 0xffffffffull));
+        }
+    }
+    for (int i = tid; i < words; i += BLK) s_removed[i] = 0ull;
+    if (tid < 64) s_mask[tid] = 0ull;
+    if (tid == 0) *s_ovf = 0u;
+    __syncthreads();
+    // slot m of this wave is chunk m*W + wv (even m) or m*W + W-1-wv (odd m) of the sorted order
+    int pos[JPT], orig[JPT];
+    float4 bj[JPT];
+    float lx = __builtin_inff(), ly = __builtin_inff(), hx = -__builtin_inff(), hy = -__builtin_inff();
+#pragma unroll
+    for (int m = 0; m < JPT; ++m) {
+        const int ch = m * W + ((m & 1) ? (W - 1 - wv) : wv);
+        pos[m] = (ch << 6) + lane;
+        bj[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+        orig[m] = 0;
+        if (pos[m] < n) {
+            orig[m] = (int)s_orig[pos[m]];
+            bj[m] = boxes[row0 + orig[m]];
+            lx = fminf(lx, bj[m].x); ly = fminf(ly, bj[m].y); hx = fmaxf(hx, bj[m].z); hy = fmaxf(hy, bj[m].w);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lx = fminf(lx, __shfl_xor(lx, o)); ly = fminf(ly, __shfl_xor(ly, o));
+        hx = fmaxf(hx, __shfl_xor(hx, o)); hy = fmaxf(hy, __shfl_xor(hy, o));
+    }
+    if (lane == 0) { s_red[wv * 4 + 0] = lx; s_red[wv * 4 + 1] = ly; s_red[wv * 4 + 2] = hx; s_red[wv * 4 + 3] = hy; }
+    __syncthreads();
+    lx = s_red[0]; ly = s_red[1]; hx = s_red[2]; hy = s_red[3];
+#pragma unroll
+    for (int w = 1; w < W; ++w) {
+        lx = fminf(lx, s_red[4 * w]); ly = fminf(ly, s_red[4 * w + 1]);
+        hx = fmaxf(hx, s_red[4 * w + 2]); hy = fmaxf(hy, s_red[4 * w + 3]);
+    }
+    // ---- 2a. centres and radii on a 15-bit grid over the extent of the segment.  With a grid that is not a sane
+    // positive number the filter passes every pair (and the queues overflow into the chunked algorithm).
+    const float E = fmaxf(hx - lx, hy - ly);
+    const bool q_ok = E > 1e-30f && E < 1e30f;
+    const float scale = q_ok ? Q_MAX / E : 0.0f;
+    const float thr_q = thr * 0.999f;
+    const float two_t = fminf(2.0f * thr_q / (1.0f + thr_q), 1.0f);      // 2 * thr / (1 + thr), at most 1
+    uint32_t cq[JPT], nj[JPT];                            // packed centre; BIAS - radius (j role)
+#pragma unroll
+    for (int m = 0; m < JPT; ++m) {
+        const float w = bj[m].z - bj[m].x, h = bj[m].w - bj[m].y;
+        uint32_t c = 0u, ri = 0u, rj = 2u * PAIR_BIAS;      // a box without positive width and height meets nobody
+        if (pos[m] < n) {
+            if (!q_ok) { ri = PAIR_BIAS; rj = 0u; }        // passes every real box (never the padding beyond n)
+            else if (w > 0.0f && h > 0.0f) {
+                const float fx = rintf(((bj[m].x + bj[m].z) * 0.5f - lx) * scale), fy = rintf(((bj[m].y + bj[m].w) * 0.5f - ly) * scale);
+                const uint32_t x = (uint32_t)fminf(fmaxf(fx, 0.0f), Q_MAX), y = (uint32_t)fminf(fmaxf(fy, 0.0f), Q_MAX);
+                c = (y << 16) | x;
+                // rounding of the two centres moves |dcx| + |dcy| by at most 2 grid units (+ fp32 slop): 1.25 per box
+                const float rad = fmaxf((w + h) * 0.5f - sqrtf(two_t * w * h), 0.0f) * 1.001f * scale;
+                const uint32_t r = (uint32_t)fminf(ceilf(rad + 1.25f), 131000.0f);
+                ri = PAIR_BIAS + r; rj = PAIR_BIAS - r;
+            }
+        }
+        if (pos[m] < ((np.max_seg + 63) & ~63)) s_irec[pos[m]] = make_uint2(c, ri);      // padding beyond n: ri = 0 passes nothing
+        cq[m] = c; nj[m] = rj;
+    }
+    __syncthreads();                                      // records visible; the sort exchange buffer is dead: queues may fill
+
+    // ---- 2b / 3. all pairs (i before j), wave-local queue
+    uint32_t *q = s_queue + wv * QCAP;
+    uint32_t nq = 0, ne = 0;                              // wave-uniform: entries in the queue; of them, tested edges at the front
+    uint32_t n_passed = 0, n_drains = 0;
+    bool ovf = false;
+    auto drain = [&]() {
+        for (uint32_t base = ne; base < nq; base += 64) {
+            const uint32_t idx = base + lane;
+            uint32_t e = 0u;
+            bool yes = false;
+            if (idx < nq) {
+                e = q[idx];
+                const int i = (int)(e >> 16), j = (int)(e & 0xffffu);
+                const float4 bi = boxes[row0 + s_orig[i]], bk = boxes[row0 + s_orig[j]];
+                const float ai = (bi.z - bi.x) * (bi.w - bi.y);
+                yes = suppresses_nodiv(bi, ai, bk, thr, k_hi, k_lo, u_min);
+            }
+            const unsigned long long ym = __ballot(yes);
+            if (yes) q[ne + __builtin_amdgcn_mbcnt_hi((uint32_t)(ym >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ym, 0u))] = e;
+            ne += (uint32_t)__popcll(ym);
+        }
+        nq = ne;
+    };
+    // The filter proper touches no scalar state: for a window of 32 boxes i, every lane shifts the outcome of each
+    // test into a 32-bit history per slot (compare into VCC, add-with-carry: three VALU per 64 pairs, no branch).
+    // The histories are then expanded into queue entries, one round per set bit of the busiest lane.
+    for (int ic = 0; ic < words && !ovf; ++ic) {
+        int m0 = JPT;
+#pragma unroll
+        for (int m = JPT - 1; m >= 0; --m)
+            if (m * W + ((m & 1) ? (W - 1 - wv) : wv) >= ic) m0 = m;
+        if (m0 == JPT) break;                              // every slot of this wave lies before chunk ic
+        const bool intra = (m0 * W + ((m0 & 1) ? (W - 1 - wv) : wv)) == ic;
+        const int c0 = ic << 6, cn = min(64, n - c0);
+        for (int t0 = 0; t0 < cn && !ovf; t0 += 32) {
+            uint32_t hist[JPT];
+#pragma unroll
+            for (int m = 0; m < JPT; ++m) hist[m] = 0u;
+            auto sweep = [&](auto first_slot) {
+                constexpr int M0 = decltype(first_slot)::value;
+                auto step = [&](const uint32_t rc, const uint32_t rr) {
+#pragma unroll
+                    for (int m = M0; m < JPT; ++m) {
+                        const uint32_t d = __builtin_amdgcn_sad_u16(rc, cq[m], nj[m]);
+                        // hist = 2 * hist + (d <= rr)
+                        uint32_t hv = hist[m];
+                        asm volatile("v_cmp_le_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+                                     : "+v"(hv) : "v"(d), "v"(rr) : "vcc");
+                        hist[m] = hv;
+                    }
+                };
+                // four records per trip, the next four already in flight (the same address in every lane: broadcast
+                // reads); records beyond n are padding that passes nothing
+                const uint4 *rp = reinterpret_cast<const uint4 *>(s_irec + c0 + t0);
+                uint4 ra = rp[0], rb = rp[1];
+#pragma unroll 2
+                for (int g = 0; g < 8; ++g) {
+                    rp += 2;
+                    const uint4 na = rp[0], nb = rp[1];
+                    step(ra.x, ra.y);
+                    step(ra.z, ra.w);
+                    step(rb.x, rb.y);
+                    step(rb.z, rb.w);
+                    ra = na; rb = nb;
+                }
+            };
+            switch (m0) {
+                case 0: sweep(std::integral_constant<int, 0>{}); break;
+                case 1: sweep(std::integral_constant<int, (JPT > 1 ? 1 : 0)>{}); break;
+                case 2: sweep(std::integral_constant<int, (JPT > 2 ? 2 : 0)>{}); break;
+                default: sweep(std::integral_constant<int, (JPT > 3 ? 3 : 0)>{}); break;
+            }
+            // bit 31 - k of a history is box i = c0 + t0 + k.  Inside box i's own chunk only the later boxes count.
+            if (intra) {
+                const int later = lane - t0;                // boxes c0 + t0 .. c0 + lane - 1 come before this lane's box
+                const uint32_t keepbits = later <= 0 ? 0u : (later >= 32 ? 0xffffffffu : (0xffffffffu << (32 - later)));
+#pragma unroll
+                for (int m = 0; m < JPT; ++m)
+                    if (m == m0) hist[m] &= keepbits;
+            }
+#pragma unroll
+            for (int m = 0; m < JPT; ++m) {
+                uint32_t hm = hist[m];
+                for (;;) {
+                    const unsigned long long act = __ballot(hm != 0u);
+                    if (act == 0ull || ovf) break;
+                    if (nq + 64u > (uint32_t)QCAP) {
+                        drain();
+                        ++n_drains;
+                        if (ne + 64u > (uint32_t)QCAP) { ovf = true; break; }
+                    }
+                    if (hm != 0u) {
+                        const int bit = 31 - __clz((int)hm);
+                        hm &= ~(1u << bit);
+                        q[nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u))] =
+                            ((uint32_t)(c0 + t0 + 31 - bit) << 16) | (uint32_t)pos[m];
+                    }
+                    nq += (uint32_t)__popcll(act);
+                    n_passed += (uint32_t)__popcll(act);
+                }
+            }
+        }
+    }
+    if (!ovf) { drain(); ++n_drains; }
+    if (lane == 0) {
+        s_ne[wv] = ne;
+        if (ovf) *s_ovf = 1u;
+        if (np.stats) {
+            atomicAdd(&g_pair_stats[2], (unsigned long long)n_passed);
+            atomicAdd(&g_pair_stats[3], (unsigned long long)ne);
+            atomicAdd(&g_pair_stats[4], (unsigned long long)n_drains);
+            if (wv == 0) atomicAdd(&g_pair_stats[0], 1ull);
+            if (ovf) atomicAdd(&g_pair_stats[1], 1ull);
+        }
+    }
+    __syncthreads();
+    if (*s_ovf) return false;
+
+    // ---- 4. resolve in score order
+    uint32_t nev[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) nev[w] = s_ne[w];
+    for (int ch = 0; ch < words; ++ch) {
+        const int c0 = ch << 6;
+        const int cn = min(64, n - c0);
+        const unsigned long long valid = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+            for (uint32_t e = tid; e < nev[w]; e += BLK) {
+                const uint32_t en = s_queue[w * QCAP + e];
+                const int i = (int)(en >> 16), j = (int)(en & 0xffffu);
+                if ((j >> 6) != ch) continue;
+                if (i >= c0) atomicOr(&s_mask[i - c0], 1ull << (j - c0));
+                else if (!((s_removed[i >> 6] >> (i & 63)) & 1ull)) atomicOr(&s_removed[ch], 1ull << (j & 63));
+            }
+        __syncthreads();
+        if (wv == 0) {
+            const unsigned long long m = s_mask[lane];
+            s_mask[lane] = 0ull;
+            unsigned long long rows = __ballot(m != 0ull);
+            unsigned long long keep = uniform64(~s_removed[ch] & valid);
+            while (rows) {                                   // only rows that suppress anything matter, in order
+                const int i = __ffsll((long long)rows) - 1;
+                rows &= rows - 1ull;
+                if ((keep >> i) & 1ull) keep &= ~readlane64(m, i);
+            }
+            if (lane == 0) s_removed[ch] = valid & ~keep;
+        }
+        __syncthreads();
+    }
+    // kept = not removed; compact in sorted order
+    if (wv == 0) {
+        uint32_t running = 0;
+        for (int base = 0; base < words; base += 64) {
+            const int w = base + lane;
+            uint32_t pc = 0;
+            if (w < words) {
+                const int cn = min(64, n - (w << 6));
+                const unsigned long long valid = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
+                pc = (uint32_t)__popcll(~s_removed[w] & valid);
+            }
+            uint32_t inc = pc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(inc, o);
+                if (lane >= o) inc += up;
+            }
+            if (w < words) s_wprefix[w] = running + inc - pc;
+            running += __shfl(inc, 63);
+        }
+        if (lane == 0) kcount[(size_t)b * np.S + s] = (int32_t)running;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < JPT; ++m) {
+        const int i = pos[m];
+        if (i >= n) continue;
+        const unsigned long long rem = s_removed[i >> 6];
+        if ((rem >> (i & 63)) & 1ull) continue;
+        const uint32_t rank = s_wprefix[i >> 6] + (uint32_t)__popcll(~rem & ((1ull << (i & 63)) - 1ull));
+        const int p = seg0 + orig[m];
+        kept[row0 + rank] = make_float2(__uint_as_float(okey_from_bits(__float_as_uint(scores[(size_t)b * np.stride + p] + 0.0f))), __int_as_float(p));
+    }
+    return true;
+}
+
+template <int JPT, int BLK>
+__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == 256 ? 5 : 1))) void nms_segments_pairs_kernel(
+    const float4 *__restrict__ boxes, const float *__restrict__ scores, const int32_t *__restrict__ seg_off,
+    NmsParams np, float2 *__restrict__ kept, int32_t *__restrict__ kcount) {
+    extern __shared__ unsigned long long s_dyn[];
+    if (nms_pairs_body<JPT, BLK>(boxes, scores, seg_off, np, kept, kcount, s_dyn)) return;
+    __syncthreads();
+    nms_chunked_body<JPT, BLK>(boxes, scores, seg_off, np, kept, kcount, s_dyn);      // heavily clustered segment
 }
 
 // Exclusive scan of the kept counts of an image's segments; a negative count marks a segment the NMS
@@ -988,6 +1371,11 @@ __global__ __launch_bounds__(256) void pack_wire_kernel(
     for (int i = threadIdx.x; i < 6 * nb; i += 256) out[i] = s_rows[i];
 }
 
+// DETBOX_NMS_CHUNKED=1 (measurements, tests): always the chunked kernel, never the pair-list one
+const bool g_nms_chunked_only = std::getenv("DETBOX_NMS_CHUNKED") != nullptr;
+// DETBOX_NMS_STATS=1: the pair-list kernel adds to the counters detbox_debug_nms_stats reads (a few atomics per wave)
+const bool g_nms_stats = std::getenv("DETBOX_NMS_STATS") != nullptr;
+
 struct NmsLayout { size_t kept_a, kept_b, kcount, koff, total; };
 
 NmsLayout nms_layout(int64_t B, int64_t stride, int64_t S) {
@@ -1054,6 +1442,7 @@ extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scor
     if ((double)t32 > iou_threshold) t32 = std::nextafterf(t32, -INFINITY);
     np.thr = t32;
     np.thr_neg = iou_threshold < 0.0 ? 1 : 0;
+    np.stats = g_nms_stats ? 1 : 0;
     const bool fast = !np.presorted && !np.thr_neg && max_segment <= DETBOX_NMS_MAX_SORT;
     {
         ProfScope ps("nms_segments", st);
@@ -1072,15 +1461,36 @@ extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scor
         nms_segments_fast_kernel<J, BLKC><<<grid, dim3(BLKC), lds, st>>>(b4, scores, seg_offsets, np, kept_a, kcount); \
     }
             const int jpt = (int)((max_segment + blk - 1) / blk);
-            if (blk == 64) {
-                if (jpt <= 1) DETBOX_NMS_FAST(1, 64)
-                else if (jpt <= 2) DETBOX_NMS_FAST(2, 64)
-                else DETBOX_NMS_FAST(4, 64)
-            } else if (jpt <= 1) DETBOX_NMS_FAST(1, 256)
-            else if (jpt <= 2) DETBOX_NMS_FAST(2, 256)
-            else if (jpt <= 4) DETBOX_NMS_FAST(4, 256)
+            // up to four slots per wave: the pair-list kernel (chunked algorithm inside it as the fall-back)
+            const size_t lds_p0 = nms_pair_lds(np.max_seg, np.n2, blk).total;
+            const size_t lds_p = lds_p0 > lds ? lds_p0 : lds;
+#define DETBOX_NMS_PAIRS(J, BLKC)                                                                                \
+    {                                                                                                            \
+        if (lds_p > 64 * 1024)                                                                                   \
+            DETBOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_segments_pairs_kernel<J, BLKC>),   \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));             \
+        nms_segments_pairs_kernel<J, BLKC><<<grid, dim3(BLKC), lds_p, st>>>(b4, scores, seg_offsets, np, kept_a, kcount); \
+    }
+            if (g_nms_chunked_only) {
+                if (blk == 64) {
+                    if (jpt <= 1) DETBOX_NMS_FAST(1, 64)
+                    else if (jpt <= 2) DETBOX_NMS_FAST(2, 64)
+                    else DETBOX_NMS_FAST(4, 64)
+                } else if (jpt <= 1) DETBOX_NMS_FAST(1, 256)
+                else if (jpt <= 2) DETBOX_NMS_FAST(2, 256)
+                else if (jpt <= 4) DETBOX_NMS_FAST(4, 256)
+                else if (jpt <= 8) DETBOX_NMS_FAST(8, 256)
+                else DETBOX_NMS_FAST(16, 256)
+            } else if (blk == 64) {
+                if (jpt <= 1) DETBOX_NMS_PAIRS(1, 64)
+                else if (jpt <= 2) DETBOX_NMS_PAIRS(2, 64)
+                else DETBOX_NMS_PAIRS(4, 64)
+            } else if (jpt <= 1) DETBOX_NMS_PAIRS(1, 256)
+            else if (jpt <= 2) DETBOX_NMS_PAIRS(2, 256)
+            else if (jpt <= 4) DETBOX_NMS_PAIRS(4, 256)
             else if (jpt <= 8) DETBOX_NMS_FAST(8, 256)
             else DETBOX_NMS_FAST(16, 256)
+#undef DETBOX_NMS_PAIRS
 #undef DETBOX_NMS_FAST
         } else {
             const size_t lds = nms_lds(np.max_seg, np.n2, np.presorted, np.in_lds).total;
@@ -1126,6 +1536,18 @@ extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scor
         DETBOX_LAUNCH_CHECK();
         float2 *tmp = src; src = dst; dst = tmp;
         group *= 2;
+    }
+    return DETBOX_OK;
+}
+
+extern "C" int detbox_debug_nms_stats(uint64_t *out8, int reset) {
+    DETBOX_CHECK_ARG(out8, "null pointer");
+    unsigned long long host[8];
+    DETBOX_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pair_stats), sizeof(host)));
+    for (int i = 0; i < 8; ++i) out8[i] = host[i];
+    if (reset) {
+        for (int i = 0; i < 8; ++i) host[i] = 0ull;
+        DETBOX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pair_stats), host, sizeof(host)));
     }
     return DETBOX_OK;
 }
