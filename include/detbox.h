@@ -266,10 +266,11 @@ int detbox_profile_read(const char *name, double *total_ms, int64_t *launches);
 int detbox_debug_stream_read(const float *in, int64_t n, float *out, int blocks, void *stream);
 
 /* Measurement aid, not part of the box-ops path: counters of the pair-list NMS kernel summed over all launches
- * on the current device since the last reset, collected while the environment variable DETBOX_NMS_STATS is set
- * (synchronises the device): out8[0] segments, [1] segments redone by
+ * on the current device since the last reset, collected while switched on (detbox_debug_nms_stats_enable, or the
+ * environment variable DETBOX_NMS_STATS at load time; a few atomics per wave).  Synchronises the device. out8[0] segments, [1] segments redone by
  * the chunked algorithm because a pair queue overflowed, [2] pairs that passed the centre-distance filter,
  * [3] pairs with iou above the threshold, [4] queue drains; [5..7] unused. */
+int detbox_debug_nms_stats_enable(int on);
 int detbox_debug_nms_stats(uint64_t *out8, int reset);
 
 #ifdef __cplusplus

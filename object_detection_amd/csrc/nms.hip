@@ -970,11 +970,13 @@ __device__ inline bool nms_pairs_body(
             atomicAdd(&g_pair_stats[3], (unsigned long long)ne);
             atomicAdd(&g_pair_stats[4], (unsigned long long)n_drains);
             if (wv == 0) atomicAdd(&g_pair_stats[0], 1ull);
-            if (ovf) atomicAdd(&g_pair_stats[1], 1ull);
         }
     }
     __syncthreads();
-    if (*s_ovf) return false;
+    if (*s_ovf) {
+        if (np.stats && tid == 0) atomicAdd(&g_pair_stats[1], 1ull);
+        return false;
+    }
 
     // ---- 4. resolve in score order
     uint32_t nev[W];
@@ -1374,7 +1376,7 @@ __global__ __launch_bounds__(256) void pack_wire_kernel(
 // DETBOX_NMS_CHUNKED=1 (measurements, tests): always the chunked kernel, never the pair-list one
 const bool g_nms_chunked_only = std::getenv("DETBOX_NMS_CHUNKED") != nullptr;
 // DETBOX_NMS_STATS=1: the pair-list kernel adds to the counters detbox_debug_nms_stats reads (a few atomics per wave)
-const bool g_nms_stats = std::getenv("DETBOX_NMS_STATS") != nullptr;
+bool g_nms_stats = std::getenv("DETBOX_NMS_STATS") != nullptr;     // also switched by detbox_debug_nms_stats_enable
 
 struct NmsLayout { size_t kept_a, kept_b, kcount, koff, total; };
 
@@ -1537,6 +1539,11 @@ extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scor
         float2 *tmp = src; src = dst; dst = tmp;
         group *= 2;
     }
+    return DETBOX_OK;
+}
+
+extern "C" int detbox_debug_nms_stats_enable(int on) {
+    g_nms_stats = on != 0;
     return DETBOX_OK;
 }
 

@@ -25,13 +25,6 @@ from . import anchors as A
 from . import ops
 
 
-def focal_loss(input, target, alpha=0.25, gamma=2, reduction='none'):
-    """src/models/losses.py:5-9."""
-    pt = F.softmax(input, dim=-1)
-    log_pt = F.log_softmax(input, dim=-1)
-    return F.nll_loss(alpha * (1 - pt).pow(gamma) * log_pt, target, reduction=reduction)
-
-
 def iou_loss_with_distance(input, target, reduction='none'):
     """src/models/losses.py:12-29 (rays ordered l, r, t, b)."""
     def area(t):
@@ -66,9 +59,27 @@ class _BoxOps:
         locs, head, extra = self._head(outputs)
         return locs, ops.activate_scores(head.contiguous(), None if extra is None else extra.contiguous(), self.activation)
 
+    # True: the activation runs inside the selection pass (the head output is read once).  False: the activation is
+    # torch's own, exactly the reference's lines (ssd300.py:354, fcos.py:314, yolov3.py:298-300), on the device the
+    # head output lives on, and the selection ranks those very bits -- for callers who need the candidate sets of a
+    # particular torch build bit for bit, at the price of one more pass over [B,P,C].
+    fused_activation = True
+
+    def _torch_scores(self, head, extra):
+        if self.activation == ops.ACT_SOFTMAX:
+            return F.softmax(head, dim=-1)
+        if self.activation == ops.ACT_SOFTMAX_SIGMOID:
+            return F.softmax(head, dim=-1) * extra.sigmoid()[..., None]
+        if self.activation == ops.ACT_SIGMOID_SIGMOID:
+            return head.sigmoid() * extra.sigmoid()[..., None]
+        return head
+
     def candidates(self, outputs: tuple, conf_thresh: float = 0.01, top_k: int = 200) -> ops.Candidates:
         locs, head, extra = self._head(outputs)
         anchors = self._table(self._anchors_for_decode(), head.device)
+        if not self.fused_activation:
+            return ops.select_decode(self._torch_scores(head, extra).contiguous(), locs.contiguous(), anchors, self.decode_mode,
+                                     self.class_begin, self.class_id_offset, conf_thresh, top_k, activation=ops.ACT_NONE)
         return ops.select_decode(head.contiguous(), locs.contiguous(), anchors, self.decode_mode,
                                  self.class_begin, self.class_id_offset, conf_thresh, top_k,
                                  activation=self.activation, extra=None if extra is None else extra.contiguous())
@@ -92,8 +103,7 @@ class _BoxOps:
             ps = [scores[b, :n] for b, n in enumerate(counts)]
             pc = [cls[b, :n] for b, n in enumerate(counts)]
         from . import predictor
-        predictor.remember((pb, ps, pc), c)              # Predictor.run continues on the device copy if handed these back
-        return pb, ps, pc
+        return predictor.remember((pb, ps, pc), c)       # Predictor.run continues on the device copy if handed these back
 
     def detect(self, outputs: tuple, image_metas: Sequence[dict], conf_thresh: float = 0.01, top_k: int = 200,
                iou_thresh: float = 0.45, trim: bool = True):

@@ -427,7 +427,7 @@ def topk_mask(values: torch.Tensor, k: torch.Tensor) -> torch.Tensor:
     """mask[b, p] = descending rank of values[b, p] in row b < k[b], ties by ascending index: the
     `values.argsort(descending=True).argsort() < k[:, None]` of the reference's hard-negative mining
     (src/models/ssd300.py:277-278) without the two sorts.  values [B, P] float, k [B] integer -> bool [B, P]."""
-    dev = _device()
+    dev = values.device if values.is_cuda else _device()
     if values.dim() != 2:
         raise ValueError('values must be [B, P]')
     B, P = values.shape
@@ -436,7 +436,8 @@ def topk_mask(values: torch.Tensor, k: torch.Tensor) -> torch.Tensor:
     if kk.numel() != B:
         raise ValueError('k must hold one count per row')
     out = torch.empty((B, P), dtype=torch.bool, device=dev)
-    _lib.check(_lib.lib().detbox_topk_mask(_ptr(v), _ptr(kk), B, P, _ptr(out), _stream(dev)), 'detbox_topk_mask')
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().detbox_topk_mask(_ptr(v), _ptr(kk), B, P, _ptr(out), _stream(dev)), 'detbox_topk_mask')
     return out if values.is_cuda else out.to(values.device)
 
 

@@ -17,27 +17,55 @@ from . import ops
 from ._lib import DetboxError
 
 
-# The lists pre_predict handed out last, with the device-resident candidates they were copied from.  When
-# Predictor.run is given those very lists back, unmodified (the flow of src/test.py:93-99), it continues on the
-# device copy instead of uploading and re-segmenting what just came down.
-_resident = None
+class CandidateList(list):
+    """One of the three lists pre_predict returns (boxes, scores or class ids per image).  It is an ordinary list
+    of CPU tensors that also keeps the device-resident candidates it was copied from, so that Predictor.run,
+    handed the three lists of one pre_predict call back unmodified (the flow of src/test.py:93-99), continues on
+    the device instead of uploading and re-segmenting what just came down.  The link lives and dies with the
+    lists: nothing is kept in the module or on the model."""
+
+    def __init__(self, items, resident=None, role=0):
+        super().__init__(items)
+        self._resident, self._role = resident, role
 
 
-def remember(lists, candidates) -> None:
-    global _resident
-    pb, ps, pc = lists
-    _resident = (pb, ps, pc, [t._version for t in (*pb, *ps, *pc)], candidates)
+class _Resident:
+    """The device candidates of one pre_predict call and a fingerprint of every tensor that was handed out."""
+
+    def __init__(self, candidates, lists):
+        self.candidates = candidates
+        self.prints = [[_fingerprint(t) for t in lst] for lst in lists]
+        self.refs = [[t for t in lst] for lst in lists]           # identity: the very tensor objects
+
+
+def _fingerprint(t: torch.Tensor):
+    # in-place operators bump the tensor's version counter; a replaced element, a slice or a copy is another object
+    return (t.data_ptr(), tuple(t.shape), t.dtype, t._version)
+
+
+def remember(lists, candidates):
+    """Wraps the three lists of a pre_predict call so that Predictor.run can find the device copy again."""
+    r = _Resident(candidates, lists)
+    return tuple(CandidateList(lst, r, role) for role, lst in enumerate(lists))
 
 
 def recall(pb, ps, pc):
-    r = _resident
-    if r is None or r[0] is not pb or r[1] is not ps or r[2] is not pc:
+    """The device candidates behind (pb, ps, pc) if these are the three lists of one pre_predict call, in their
+    roles, with every element still the tensor that was handed out and untouched by in-place operators; else None
+    (the generic path then uploads the lists, which is always correct).  Writes through views that bypass the
+    version counter (`.numpy()`, `.data`) are not seen: pass plain lists (`list(pb)`) after such edits."""
+    r = getattr(pb, '_resident', None)
+    if r is None or getattr(ps, '_resident', None) is not r or getattr(pc, '_resident', None) is not r:
         return None
-    c = r[4]
-    B = c.boxes.shape[0]
-    if not (len(pb) == len(ps) == len(pc) == B) or [t._version for t in (*pb, *ps, *pc)] != r[3]:
+    if (getattr(pb, '_role', -1), getattr(ps, '_role', -1), getattr(pc, '_role', -1)) != (0, 1, 2):
         return None
-    return c
+    for lst, refs, prints in zip((pb, ps, pc), r.refs, r.prints):
+        if len(lst) != len(refs):
+            return None
+        for t, ref, fp in zip(lst, refs, prints):
+            if t is not ref or _fingerprint(t) != fp:
+                return None
+    return r.candidates
 
 
 def rows_to_dicts(rows_ids: torch.Tensor, rows_vals: torch.Tensor) -> List[dict]:

@@ -179,7 +179,7 @@ def check_no_boundary_tie(confs, class_begin, conf_thresh, top_k):
 
 
 def predict_case(name, run_pre_predict, anchors_hash, spec, metas, out, activated, class_begin,
-                 conf_thresh, top_k, store_inputs=None):
+                 conf_thresh, top_k, store_inputs=None, big=False):
     bboxes, scores, class_ids = run_pre_predict()
     check_no_boundary_tie(activated, class_begin, conf_thresh, top_k)
     counts = np.array([b.shape[0] for b in bboxes], dtype=np.int32)
@@ -190,12 +190,40 @@ def predict_case(name, run_pre_predict, anchors_hash, spec, metas, out, activate
         k_v = O.batched_nms(b, s, c, 0.45)
         k_t = O.batched_nms_coordinate_trick(b, s, c, 0.45)
         if not torch.equal(k_v, k_t):
-            raise AssertionError(f'{name}: per-class and coordinate-trick NMS disagree; pick another seed')
+            # the coordinate-offset form rounds boxes of high class ids differently; torchvision >= 0.10 takes the per-class
+            # form whenever boxes.numel() > 4000, which every full-size fixture exceeds by far
+            if not big:
+                raise AssertionError(f'{name}: per-class and coordinate-trick NMS disagree; pick another seed')
+            spec['coordinate_trick_agrees'] = False
         keeps.append(k_v)
     keep_counts = np.array([k.numel() for k in keeps], dtype=np.int32)
     assert int(keep_counts.sum()) == len(result)
     rows_ids = np.array([[r['image_id'], r['category_id']] for r in result], dtype=np.int64).reshape(-1, 2)
     rows_vals = np.array([r['bbox'] + [r['score']] for r in result], dtype=np.float64).reshape(-1, 5)
+    if big:
+        # full-size configurations: hashes of the full arrays, a regular subsample, and the keep lists as one bit per
+        # candidate (the order of a keep list is the stable descending-score order of its members)
+        ab, asc, ac, ak = torch.cat(bboxes), torch.cat(scores), torch.cat(class_ids), torch.cat(keeps)
+        mask = np.zeros(int(counts.sum()), dtype=np.uint8)
+        off = 0
+        for n, k in zip(counts, keeps):
+            mask[off + k.numpy()] = 1
+            off += int(n)
+        for b_, s_, k in zip(bboxes, scores, keeps):            # the keep order really is what the bitmap implies
+            members = torch.sort(k).values
+            assert torch.equal(members[torch.argsort(s_[members], descending=True, stable=True)], k)
+        sub = slice(0, None, 16)
+        d = dict(spec=np.array(json.dumps(spec)), anchors_sha256=np.array(anchors_hash), counts=counts,
+                 bboxes_sha256=np.array(sha(ab)), scores_sha256=np.array(sha(asc)),
+                 class_ids_sha256=np.array(sha(ac.to(torch.int64))),
+                 sub_bboxes=ab[sub].numpy(), sub_scores=asc[sub].numpy(), sub_class_ids=ac[sub].numpy().astype(np.int16),
+                 keep_counts=keep_counts, keep_bits=np.packbits(mask),
+                 rows_ids_sha256=np.array(hashlib.sha256(rows_ids.tobytes()).hexdigest()),
+                 rows_vals_sha256=np.array(hashlib.sha256(rows_vals.tobytes()).hexdigest()),
+                 sub_rows_ids=rows_ids[sub], sub_rows_vals=rows_vals[sub], metas=np.array(json.dumps(metas)))
+        np.savez_compressed(os.path.join(HERE, f'predict_{name}.npz'), **d)
+        out[f'predict_{name}'] = dict(counts=counts.tolist(), keep_counts=keep_counts.tolist())
+        return
     d = dict(spec=np.array(json.dumps(spec)), anchors_sha256=np.array(anchors_hash),
              counts=counts, bboxes=torch.cat(bboxes).numpy(), scores=torch.cat(scores).numpy(),
              class_ids=torch.cat(class_ids).numpy().astype(np.int16),
@@ -209,7 +237,12 @@ def predict_case(name, run_pre_predict, anchors_hash, spec, metas, out, activate
 
 
 def main():
+    """With --only NAME[,NAME...] just those fixtures are (re)written and the manifest entries of the others are
+    kept: a .npz archive is not byte-reproducible (timestamps), so fixtures already committed are left alone."""
     torch.manual_seed(0)
+    only = None
+    if '--only' in sys.argv:
+        only = set(sys.argv[sys.argv.index('--only') + 1].split(','))
     manifest = {'torch': torch.__version__, 'notes': {}}
 
     # ---------------- anchor tables ----------------
@@ -236,6 +269,15 @@ def main():
 
     # ---------------- target assignment ----------------
     out = {}
+    assign_case_, predict_case_ = globals()['assign_case'], globals()['predict_case']
+
+    def assign_case(name, *a, **kw):            # honours --only
+        if only is None or f'assign_{name}' in only:
+            assign_case_(name, *a, **kw)
+
+    def predict_case(name, *a, **kw):
+        if only is None or f'predict_{name}' in only:
+            predict_case_(name, *a, **kw)
     # hand-made SSD300 cases: exact default-box hit, two GTs sharing one best box,
     # a tiny GT whose best IoU is < 0.5 (forced match keeps the arg-max GT's label), a box leaving the image
     d = ssd300.dboxes
@@ -296,6 +338,21 @@ def main():
     predict_case('fcos512', lambda: fcos512.pre_predict((locs.clone(), confs.clone(), cents.clone())),
                  H['fcos512_points'], spec, metas2, out, act, 1, 0.01, 200)
 
+    # the full-size configurations of the headline metric (hashes + subsample)
+    metas1 = metas2[:1]
+    locs, confs, cents = head_outputs(2004, 2, 13343, 81, sparse_images=(1,), extra=True, bg_bias=2.0, loc_bias=3.0)
+    spec = dict(family='fcos', f_k=fk800, B=2, C=81, seed=2004, sparse_images=[1], bg_bias=2.0, loc_bias=3.0, conf_thresh=0.01, top_k=200,
+                inputs_sha256=[sha(locs), sha(confs), sha(cents)])
+    act = torch.softmax(confs, -1) * cents.sigmoid()[..., None]
+    predict_case('fcos800', lambda: fcos800.pre_predict((locs.clone(), confs.clone(), cents.clone())),
+                 H['fcos800_points'], spec, metas2, out, act, 1, 0.01, 200, big=True)
+
+    locs, confs, _ = head_outputs(2005, 1, 120087, 81)
+    spec = dict(family='retinanet', f_k=fk800, B=1, C=81, seed=2005, sparse_images=[], bg_bias=8.0, conf_thresh=0.01, top_k=1000,
+                inputs_sha256=[sha(locs), sha(confs)])
+    predict_case('retinanet800', lambda: ret800.pre_predict((locs.clone(), confs.clone()), top_k=1000),
+                 H['retinanet800_pboxes'], spec, metas1, out, torch.softmax(confs, -1), 1, 0.01, 1000, big=True)
+
     # YoloV3.pre_predict has no runnable reference behaviour
     locs, confs, objs = head_outputs(2003, 1, 10647, 20, extra=True, yolo=True)
     try:
@@ -304,6 +361,11 @@ def main():
     except TypeError as e:
         manifest['notes']['yolov3_pre_predict'] = f'TypeError: {e}'
 
+    if only is not None:
+        with open(os.path.join(HERE, 'manifest.json')) as f:
+            old = json.load(f)
+        old['cases'].update(out)
+        manifest, out = old, old['cases']
     manifest['cases'] = out
     with open(os.path.join(HERE, 'manifest.json'), 'w') as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

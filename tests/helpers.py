@@ -125,3 +125,47 @@ def rows_from_detections(per_image, image_ids, image_sizes):
         vals.append(torch.stack([bx[:, 0].double() * W, bx[:, 1].double() * H, (bx[:, 2] - bx[:, 0]).double() * W,
                                  (bx[:, 3] - bx[:, 1]).double() * H, scores.to(torch.float32).double()], dim=1))
     return torch.cat(ids), torch.cat(vals)
+
+
+def big_predict_reference(O, z, anchors, strict=False):
+    """Full-size predict_* fixtures hold hashes, a subsample and the keep lists as one bit per candidate.  The
+    reference's full arrays are rebuilt here by the CPU oracle from the seeded inputs.  On the machine that made
+    the fixtures (strict=True, the CPU suite) every hash must be reproduced bit for bit, which pins the oracle at
+    full size.  On another CPU torch's exp / soft-max may round differently (another vector ISA), so there the
+    integer results must match exactly and the float arrays agree with the stored subsample to 1e-6.  Returns
+    (spec, inputs (locs, confs, ext), lists (boxes, scores, class ids per image), keeps per image, rows_ids, rows_vals)."""
+    import hashlib
+    spec, locs, confs, ext = predict_inputs(z, anchors.shape[0])
+    thr, k = spec['conf_thresh'], spec['top_k']
+    if spec['family'] == 'fcos':
+        pb, ps, pc = O.pre_predict_fcos(locs, confs, ext, anchors, thr, k, fast=True)
+    else:
+        pb, ps, pc = O.pre_predict_softmax(locs, confs, anchors, thr, k, fast=True)
+    counts = z['counts'].tolist()
+    assert [t.shape[0] for t in pb] == counts
+    ab, asc, ac = torch.cat(pb), torch.cat(ps), torch.cat(pc)
+    assert sha(ac) == str(z['class_ids_sha256'])
+    exact = sha(ab) == str(z['bboxes_sha256']) and sha(asc) == str(z['scores_sha256'])
+    assert exact or not strict
+    assert rel_close(asc[::16], torch.from_numpy(z['sub_scores']), 1e-6, atol=0.0)
+    assert box_close(ab[::16], torch.from_numpy(z['sub_bboxes']), 1e-6)
+    bits = torch.from_numpy(np.unpackbits(z['keep_bits'])[:sum(counts)].astype(bool))
+    keeps = []
+    for m, s_ in zip(split(bits, counts), ps):
+        members = torch.nonzero(m).flatten()
+        keeps.append(members[torch.argsort(s_[members], descending=True, stable=True)])
+    assert [k_.numel() for k_ in keeps] == z['keep_counts'].tolist()
+    metas = json.loads(str(z['metas']))
+    ids, vals = [], []
+    for meta, b, s_, c, kp in zip(metas, pb, ps, pc, keeps):       # the rows of src/utilities/predictor.py:56-73 for these keep lists
+        bb, ss, cc = b[kp], s_[kp], c[kp]
+        H, W = meta['height'], meta['width']
+        ids.append(torch.stack([torch.full_like(cc, meta['image_id']), cc], dim=1))
+        vals.append(torch.stack([bb[:, 0].double() * W, bb[:, 1].double() * H, (bb[:, 2] - bb[:, 0]).double() * W,
+                                 (bb[:, 3] - bb[:, 1]).double() * H, ss.double()], dim=1))
+    rid, rv = torch.cat(ids), torch.cat(vals)
+    if exact:
+        assert hashlib.sha256(rid.numpy().tobytes()).hexdigest() == str(z['rows_ids_sha256'])
+        assert hashlib.sha256(rv.numpy().tobytes()).hexdigest() == str(z['rows_vals_sha256'])
+        assert np.array_equal(rid[::16].numpy(), z['sub_rows_ids']) and np.array_equal(rv[::16].numpy(), z['sub_rows_vals'])
+    return spec, (locs, confs, ext), (pb, ps, pc), keeps, rid, rv

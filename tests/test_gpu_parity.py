@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import box_close, head_outputs, load, predict_inputs, rel_close, sha, split, unpack_gt
+from helpers import big_predict_reference, box_close, head_outputs, load, predict_inputs, rel_close, sha, split, unpack_gt
 
 pytestmark = pytest.mark.gpu
 
@@ -375,6 +375,87 @@ def test_from_logits_end_to_end_matches_golden(D, oracle, dev, name, table):
         go, wo = go + gn, wo + wn
 
 
+@pytest.mark.parametrize('name,table', [('fcos800', 'fcos800_points'), ('retinanet800', 'retinanet800_pboxes')])
+def test_from_logits_end_to_end_full_size(D, oracle, dev, name, table):
+    """FCOS-800 (P = 13343, C = 81, soft-max x sigmoid, top-200) and RetinaNet-800 (P = 120087, C = 81, top-1000) from
+    raw logits through the shipped path, against what the reference itself produced (hashes, subsample and keep
+    bitmaps in the fixture; the full arrays come from the oracle, which must reproduce every hash first)."""
+    import e2e_compare as E
+    z = load('predict_' + name)
+    anchors = tables(D.anchors)[table]()
+    spec, (locs, confs, ext), ref_lists, ref_keeps, want_ids, want_vals = big_predict_reference(oracle, z, anchors)
+    m = golden_model(D, spec)
+    assert sha(m._anchors_for_decode()) == str(z['anchors_sha256'])
+    thr, k = spec['conf_thresh'], spec['top_k']
+    outs_cpu = (locs, confs) + ((ext,) if ext is not None else ())
+    # (a) the reference's own score bits (CPU activation) through the HIP selection: the candidate lists are the reference's
+    act = torch_activation(m, outs_cpu)
+    _, pb, ps, pc = hip_select(D, dev, act, locs, anchors, m.decode_mode, 1, 0, thr, k)
+    for b in range(len(pb)):
+        assert torch.equal(pc[b], ref_lists[2][b]) and torch.equal(ps[b], ref_lists[1][b])
+        assert box_close(pb[b], ref_lists[0][b], RTOL)
+    # (b) the shipped path from the raw logits
+    reports, (pb, ps, pc), keeps = from_logits_reports(D, dev, m, outs_cpu, thr, k, ref_lists, ref_keeps)
+    print(name, E.summarise(reports), [r['first_divergence'] for r in reports])
+    assert not any(r['unexplained'] for r in reports), [r['unexplained'] for r in reports]
+    metas = json.loads(str(z['metas']))
+    rid, rv = m.detect(tuple(o.to(dev) for o in outs_cpu), metas, thr, k)
+    go = wo = 0
+    for b, r in enumerate(reports):
+        gn, wn = keeps[b].numel(), ref_keeps[b].numel()
+        if r['selection_diff'] == 0 and r['keep_differing'] == 0:
+            assert torch.equal(rid[go:go + gn].cpu(), want_ids[wo:wo + wn])
+            assert rel_close(rv[go:go + gn, 4].cpu(), want_vals[wo:wo + wn, 4], RTOL, atol=0.0)
+        go, wo = go + gn, wo + wn
+
+
+def test_retinanet800_batch512_properties(D, oracle, dev):
+    """The batch-512 configuration of the sweep (RetinaNet-800, 512 images on one GPU, ~20 GB of logits): too large
+    for the oracle, so the result is pinned through what does not depend on the batch -- every image of the batch
+    must give exactly what it gives in a batch of its own size class -- and through the invariants of the path."""
+    m = D.RetinaNet(80, [100, 50, 25, 13, 7])
+    P, C, B, k = m.pboxes.shape[0], 81, 512, 1000
+    g = torch.Generator(device=dev).manual_seed(99)
+    locs = torch.randn(B, P, 4, generator=g, device=dev)
+    confs = torch.randn(B, P, C, generator=g, device=dev)
+    confs[1::2, :, 0] += 8.0                                       # every other image: the threshold binds, not top-k
+    c = m.candidates((locs, confs), 0.01, k)
+    keep, kc = D.ops.nms_candidates(c, 0.45)
+    counts, kcs = c.counts.cpu(), kc.cpu()
+    assert bool((kcs >= 0).all()) and bool((kcs <= counts).all())
+    assert int(counts[0::2].min()) == 80 * k                       # dense images: every class fills its top-k
+    seg = c.seg_offsets.cpu()
+    assert bool((seg[:, 1:] >= seg[:, :-1]).all()) and torch.equal(seg[:, -1], counts)
+    # kept indices are in descending score order and inside the image's candidates
+    for b in (0, 1, 255, 511):
+        kb = keep[b, :int(kcs[b])]
+        assert int(kb.max()) < int(counts[b]) and int(kb.min()) >= 0
+        sb = c.scores[b][kb]
+        assert bool((sb[1:] <= sb[:-1]).all())
+    # batch independence: images 0, 1, 255, 511 alone give bit-identical candidates and keep lists
+    pick = [0, 1, 255, 511]
+    c2 = m.candidates((locs[pick].contiguous(), confs[pick].contiguous()), 0.01, k)
+    keep2, kc2 = D.ops.nms_candidates(c2, 0.45)
+    for i, b in enumerate(pick):
+        n = int(counts[b])
+        assert int(c2.counts[i]) == n and int(kc2[i]) == int(kcs[b])
+        assert torch.equal(c2.scores[i, :n], c.scores[b, :n]) and torch.equal(c2.class_ids[i, :n], c.class_ids[b, :n])
+        assert torch.equal(c2.boxes[i, :n], c.boxes[b, :n])
+        assert torch.equal(keep2[i, :int(kc2[i])], keep[b, :int(kcs[b])])
+    # and the oracle on two of them (one dense, one sparse)
+    _, ascores = m._activate((locs[:2].contiguous(), confs[:2].contiguous()))
+    want = oracle_select(oracle, ascores.cpu(), locs[:2].cpu(), m.pboxes, 0, 1, 0, 0.01, k)
+    got = ([c.boxes[b, :int(counts[b])].cpu() for b in (0, 1)], [c.scores[b, :int(counts[b])].cpu() for b in (0, 1)],
+           [c.class_ids[b, :int(counts[b])].cpu() for b in (0, 1)])
+    check_select(got, want)
+    for b in (0, 1):
+        wk = oracle.batched_nms(got[0][b], got[1][b], got[2][b], 0.45)
+        assert torch.equal(keep[b, :int(kcs[b])].cpu(), wk)
+    del locs, confs, c, c2, keep, keep2
+    torch.cuda.empty_cache()
+    D.ops._workspaces.clear()
+
+
 def test_select_ties_and_degenerate_inputs(D, oracle, dev):
     O = oracle
     anchors = D.anchors.retinanet_prior_boxes([16, 8, 4, 2, 1])     # 3069 anchors
@@ -581,6 +662,36 @@ def test_nms_adversarial_geometry(D, oracle, dev):
         want = O.batched_nms(boxes, scores, idxs, 0.45)
         got = D.batched_nms(boxes.to(dev), scores.to(dev), idxs.to(dev), 0.45)
         assert torch.equal(got.cpu(), want), ncls
+
+
+def test_nms_pair_list_and_its_fall_back(D, oracle, dev):
+    """The pair-list kernel handles scattered boxes by itself; heavily clustered boxes (more true suppressions than a
+    wave's queue holds) are redone by the chunked algorithm inside the same launch.  Both against the oracle, with the
+    kernel's own counters telling which path ran."""
+    import ctypes
+    O = oracle
+    L = D.ops._lib.lib()
+    g = torch.Generator().manual_seed(123)
+    out = (ctypes.c_uint64 * 8)()
+    L.detbox_debug_nms_stats_enable(1)
+    try:
+        def run(boxes, scores, idxs):
+            L.detbox_debug_nms_stats(out, 1)
+            got = D.batched_nms(boxes.to(dev), scores.to(dev), idxs.to(dev), 0.45)
+            L.detbox_debug_nms_stats(out, 1)
+            assert torch.equal(got.cpu(), O.batched_nms(boxes, scores, idxs, 0.45))
+            return [int(x) for x in out]
+        n = 2400                                            # about 800 a class: the pair-list kernel covers up to 1024
+        idxs = torch.randint(0, 3, (n,), generator=g)
+        st = run(rand_boxes(g, n, spread=1.0, size=0.1), torch.rand(n, generator=g), idxs)
+        assert st[0] == 3 and st[1] == 0 and st[3] <= st[2]            # three segments, no fall-back, edges among the passed pairs
+        centres = torch.rand(12, 2, generator=g)[torch.randint(0, 12, (n,), generator=g)]
+        c = centres + 0.004 * torch.randn(n, 2, generator=g)
+        wh = 0.2 + 0.01 * torch.rand(n, 2, generator=g)
+        st = run(torch.cat([c - wh / 2, c + wh / 2], 1), torch.rand(n, generator=g), idxs)
+        assert st[0] == 3 and st[1] == 3                                # every segment overflowed and was redone
+    finally:
+        L.detbox_debug_nms_stats_enable(0)
 
 
 def test_nms_thousands_of_short_segments(D, oracle, dev):
@@ -1042,6 +1153,12 @@ def test_predictor_continues_on_the_device_copy(D, oracle, dev):
     assert len(fast) > 0 and fast == generic
     want = oracle.predictor_run(metas, pb, ps, pc, 0.45)
     assert [(r['image_id'], r['category_id']) for r in fast] == [(r['image_id'], r['category_id']) for r in want]
+    # element replacement (a fresh tensor or a slice in the same list object) is honoured as well
+    pb2, ps2, pc2 = m.pre_predict(outs, 0.05, 100)
+    pb2[0], ps2[0], pc2[0] = pb2[0][:50], ps2[0][:50], pc2[0][:50]
+    ps2[2] = ps2[2].clamp(max=0.5)
+    assert PR.recall(pb2, ps2, pc2) is None
+    assert pred.run(metas, pb2, ps2, pc2) == oracle.predictor_run(metas, list(pb2), list(ps2), list(pc2), 0.45)
     ps[1][0] = 0.999                                          # an in-place edit: the device copy no longer applies
     assert PR.recall(pb, ps, pc) is None
     edited = pred.run(metas, pb, ps, pc)

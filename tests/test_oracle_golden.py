@@ -100,6 +100,24 @@ def test_pre_predict_and_predictor_match_reference(oracle, name, table, fast):
     assert np.array_equal(rid.numpy(), z['rows_ids']) and np.array_equal(rv.numpy(), z['rows_vals'])
 
 
+BIG_PREDICT = [('fcos800', 'fcos800_points'), ('retinanet800', 'retinanet800_pboxes')]
+
+
+@pytest.mark.parametrize('name,table', BIG_PREDICT)
+def test_full_size_pre_predict_and_predictor_match_reference(oracle, name, table):
+    """FCOS-800 (P = 13343, C = 81, top-200) and RetinaNet-800 (P = 120087, C = 81, top-1000): the reference's own
+    pre_predict + Predictor.run outputs, held as hashes + a subsample + keep bitmaps, reproduced by the oracle."""
+    from helpers import big_predict_reference
+    z = load('predict_' + name)
+    anchors = tables(oracle)[table]()
+    assert sha(anchors) == str(z['anchors_sha256'])
+    spec, _, lists, keeps, rid, rv = big_predict_reference(oracle, z, anchors, strict=True)
+    assert rid.shape[0] == int(z['keep_counts'].sum())
+    # the keep lists the bitmap implies are the oracle's own NMS
+    for b in range(len(keeps)):
+        assert torch.equal(oracle.batched_nms(lists[0][b], lists[1][b], lists[2][b], 0.45), keeps[b])
+
+
 def test_nms_c_matches_python_twin(oracle):
     O = oracle
     g = torch.Generator().manual_seed(3)
