@@ -210,7 +210,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-extra', action='store_true', help='skip the `workloads` object (the other headline configurations)')
     ap.add_argument('--graph', action='store_true',
                     help='N=1 only: capture one step per stream in a HIP graph and replay it in the timed region (launch-bound workloads)')
-    ap.add_argument('--streams', type=int, default=2,
+    ap.add_argument('--streams', type=int, default=3,
                     help='steps are issued round-robin on this many HIP streams (independent batches in flight)')
     ap.add_argument('--exchange', default='all', choices=['all', 'root'],
                     help='N>1: every rank receives the detections of all ranks (all-gather), or only rank 0 does (gather)')

@@ -576,11 +576,19 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
     for_each_subtile<ACT, EPT>(
         in, extra, b, sp.P, C, sp.total_floats, sub0, sub1, 1, s_dynf, sp.tile_floats,
         [&](float (&x)[EPT], bool valid, int r0, const RowCtx &ctx) {
-            unsigned long long pm = 0ull;               // bit i: element i is staged
-            if (valid) {
+            // bit i: element i is staged.  Built high element first with compare-into-VCC + add-with-carry
+            // (pm = 2 * pm + (x >= t)): two VALU per element, no select chains
+            uint32_t pm_lo = 0u, pm_hi = 0u;
 #pragma unroll
-                for (int i = 0; i < EPT; ++i) pm |= (unsigned long long)(x[i] >= tlo[i]) << i;
+            for (int i = EPT - 1; i >= 0; --i) {
+                if (i >= 32)
+                    asm volatile("v_cmp_ge_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+                                 : "+v"(pm_hi) : "v"(x[i]), "v"(tlo[i]) : "vcc");
+                else
+                    asm volatile("v_cmp_ge_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+                                 : "+v"(pm_lo) : "v"(x[i]), "v"(tlo[i]) : "vcc");
             }
+            unsigned long long pm = valid ? (((unsigned long long)pm_hi << 32) | pm_lo) : 0ull;
             // round k appends the k-th candidate of every lane that still has one
             unsigned long long has = __ballot(pm != 0ull);
             const uint32_t p = (uint32_t)(r0 + r);
