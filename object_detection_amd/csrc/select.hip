@@ -45,6 +45,7 @@ constexpr int MAX_TILE_ANCHORS = 16384;
 constexpr int SCAN_BLOCK = 256;
 constexpr int LPR = 4;                // lanes that share one anchor row (8 was measured: no faster)
 constexpr int SUB_ROWS = SCAN_BLOCK / LPR;   // anchors per LDS sub-tile
+constexpr int SCAN_EBUF = 256;        // entries of a scan wave's staging buffer in LDS
 constexpr int SAMPLE_SUBS = 4;        // sampled sub-tiles per workgroup of select_sample
 constexpr int BITMAP_MAX_WORDS = 4096;  // finalize orders by anchor through a P-bit LDS bitmap up to this
 
@@ -561,7 +562,14 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
     const int wv = tid >> 6;
     const uint32_t wcap = (uint32_t)sp.blk_cap >> 2;
     unsigned long long *wlist = blk_list + blk * sp.blk_cap + (size_t)wv * wcap;
-    uint32_t wn = 0;
+    uint32_t wn = 0, ln = 0;                              // entries flushed to the list; entries waiting in the LDS buffer
+    unsigned long long *ebuf = reinterpret_cast<unsigned long long *>(s_dynf + 2 * (size_t)sp.tile_floats + 4) + (size_t)wv * SCAN_EBUF;
+    auto flush = [&]() {
+        for (uint32_t k = (uint32_t)(tid & 63); k < ln; k += 64u)
+            if (wn + k < wcap) wlist[wn + k] = ebuf[k];
+        wn += ln;
+        ln = 0u;
+    };
     // the lane's classes never change: their staging thresholds live in registers
     const int r = tid / LPR, sub = tid % LPR;
     float tlo[EPT];
@@ -589,22 +597,27 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
                                  : "+v"(pm_lo) : "v"(x[i]), "v"(tlo[i]) : "vcc");
             }
             unsigned long long pm = valid ? (((unsigned long long)pm_hi << 32) | pm_lo) : 0ull;
-            // round k appends the k-th candidate of every lane that still has one
+            // round k appends the k-th candidate of every lane that still has one.  Entries go to the wave's buffer in
+            // LDS first: a global store inside the loop would be waited for at the sub-tile's barrier (the counter
+            // that tells the tile's DMA has landed counts stores as well), once per sub-tile; the buffer is flushed
+            // once per dozen sub-tiles instead.
             unsigned long long has = __ballot(pm != 0ull);
             const uint32_t p = (uint32_t)(r0 + r);
             while (has) {
+                if (ln + 64u > (uint32_t)SCAN_EBUF) flush();
                 if (pm) {
-                    const uint32_t slot = wn + __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0u));
+                    const uint32_t slot = ln + __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0u));
                     const int i = __ffsll((long long)pm) - 1;
                     pm &= pm - 1ull;
                     const float sc = rescore<ACT>(ctx, i);               // same arithmetic as x[i], bit for bit
-                    if (slot < wcap) wlist[slot] = pack_entry(okey(sc) - key_thr, (uint32_t)(sub + LPR * i - cb), p);
+                    ebuf[slot] = pack_entry(okey(sc) - key_thr, (uint32_t)(sub + LPR * i - cb), p);
                 }
-                wn += (uint32_t)__popcll(has);
+                ln += (uint32_t)__popcll(has);
                 has = __ballot(pm != 0ull);
             }
         },
         [](long long) {});
+    flush();
     if ((tid & 63) == 0) {
         blk_cnt[blk * 4 + wv] = wn < wcap ? wn : wcap;
         if (wn > wcap) img_ovf[b] = 1u;                   // the image falls back to the exact path
@@ -1143,7 +1156,7 @@ int64_t scan_resident_workgroups(int64_t C) {
             n = 256;
         cus = n;
     }
-    const size_t lds = 2 * (size_t)tile_floats_for(C) * 4 + 16;
+    const size_t lds = 2 * (size_t)tile_floats_for(C) * 4 + 16 + (size_t)(SCAN_BLOCK / 64) * SCAN_EBUF * 8;
     int64_t per_cu = (int64_t)((160 * 1024) / lds);
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
@@ -1268,7 +1281,7 @@ struct LaunchFast {
         }
         const unsigned gx = (unsigned)sp.scan_gx;
         if (sp.use_sample) {
-            const size_t lds = 2 * tile_bytes + 16;
+            const size_t lds = 2 * tile_bytes + 16 + (size_t)(SCAN_BLOCK / 64) * SCAN_EBUF * 8;
             if (int rc = set_lds(select_scan_kernel<ACT, EPT>, lds)) return rc;
             {
                 ProfScope ps("select_scan", s);
