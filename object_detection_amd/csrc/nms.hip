@@ -1182,17 +1182,55 @@ __global__ __launch_bounds__(MP_THREADS) void nms_merge_kernel(
 constexpr int ML_THREADS = 1024;
 constexpr int ML_CAP = 8192;               // elements per LDS buffer (two buffers of 64 KiB)
 
+constexpr int ML_SCAN_MAX = 2048;          // segments per image up to which the kernel scans the kept counts itself
+
 __global__ __launch_bounds__(ML_THREADS) void nms_merge_lds_kernel(
     const float2 *__restrict__ src, float2 *__restrict__ dst, int64_t *__restrict__ keep_out,
-    const int32_t *__restrict__ koff, const int32_t *__restrict__ seg_off, int S, long long stride, int F, int last) {
+    int32_t *__restrict__ koff, const int32_t *__restrict__ seg_off, int S, long long stride, int F, int last,
+    const int32_t *__restrict__ kcount, int32_t *__restrict__ keep_counts) {
     extern __shared__ float2 s_ml[];
     __shared__ int s_off[65];                // run boundaries inside the buffer (F <= 64)
+    __shared__ int s_koff[ML_SCAN_MAX + 1];
+    __shared__ int s_wsum[ML_THREADS / 64];
+    __shared__ int s_bad;
     float2 *cur = s_ml, *nxt = s_ml + ML_CAP;
     const int b = blockIdx.y, tid = threadIdx.x;
     const int s0 = blockIdx.x * F;
     if (s0 >= S) return;
     const int s1 = min(S, s0 + F);
     const int32_t *ko = koff + (size_t)b * (S + 1);
+    if (kcount) {
+        // The exclusive scan of the image's kept counts (what nms_scan_kernel does), by every workgroup for itself; the
+        // first one also leaves it in global memory for the merge levels and the packing that follow.  A negative count
+        // marks a segment the NMS kernel refused: it counts as empty and turns the image's keep count into -1.
+        const int32_t *kc = kcount + (size_t)b * S;
+        const int e0 = 2 * tid, lane = tid & 63, wave = tid >> 6;
+        int c0 = e0 < S ? kc[e0] : 0, c1 = e0 + 1 < S ? kc[e0 + 1] : 0;
+        if (tid == 0) s_bad = 0;
+        __syncthreads();
+        if (c0 < 0 || c1 < 0) s_bad = 1;
+        c0 = max(c0, 0); c1 = max(c1, 0);
+        int inc = c0 + c1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(inc, o);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        int base = inc - (c0 + c1);
+        for (int w = 0; w < wave; ++w) base += s_wsum[w];
+        if (e0 < S) s_koff[e0] = base;
+        if (e0 + 1 < S) s_koff[e0 + 1] = base + c0;
+        if (e0 < S && e0 + 2 >= S) s_koff[S] = base + c0 + c1;
+        __syncthreads();
+        if (blockIdx.x == 0) {
+            int32_t *kog = koff + (size_t)b * (S + 1);
+            for (int i = tid; i <= S; i += ML_THREADS) kog[i] = s_koff[i];
+            if (tid == 0) keep_counts[b] = s_bad ? -1 : s_koff[S];
+        }
+        ko = s_koff;
+    }
     const int32_t *so = seg_off + (size_t)b * (S + 1);
     const size_t base = (size_t)b * stride;
     const int out0 = ko[s0];
@@ -1503,16 +1541,17 @@ extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scor
         }
         DETBOX_LAUNCH_CHECK();
     }
-    {
+    long long F = 1;                       // as many merge levels as fit in LDS at once
+    while (F * 2 * max_segment <= ML_CAP && F < 64 && F < S) F *= 2;
+    const bool scan_in_merge = F > 1 && S <= ML_SCAN_MAX;
+    if (!scan_in_merge) {
         ProfScope ps("nms_scan", st);
         nms_scan_kernel<<<dim3((unsigned)B), dim3(64), 0, st>>>(kcount, (int)S, koff, keep_counts);
         DETBOX_LAUNCH_CHECK();
     }
     float2 *src = kept_a, *dst = kept_b;
     long long group = 1;
-    {   // as many levels as fit in LDS at once
-        long long F = 1;
-        while (F * 2 * max_segment <= ML_CAP && F < 64 && F < S) F *= 2;
+    {
         if (F > 1) {
             const int last = F >= S ? 1 : 0;
             const size_t lds = 2 * (size_t)ML_CAP * sizeof(float2);
@@ -1520,7 +1559,7 @@ extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scor
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ProfScope ps("nms_merge", st);
             nms_merge_lds_kernel<<<dim3((unsigned)((S + F - 1) / F), (unsigned)B), dim3(ML_THREADS), lds, st>>>(
-                src, dst, keep, koff, seg_offsets, (int)S, stride, (int)F, last);
+                src, dst, keep, koff, seg_offsets, (int)S, stride, (int)F, last, scan_in_merge ? kcount : nullptr, keep_counts);
             DETBOX_LAUNCH_CHECK();
             float2 *tmp = src; src = dst; dst = tmp;
             group = F;
