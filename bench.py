@@ -192,8 +192,9 @@ def measured_traffic(workload, regime, kernel):
 
 KERNELS = ['assign_anchor', 'assign_fixup', 'assign_fcos', 'select_sample', 'select_plan', 'select_scan',
            'select_bucket', 'select_check', 'select_fallback', 'select_materialize', 'score_hist', 'select_kth',
-           'select_refine', 'select_emit', 'select_finalize', 'nms_segments', 'nms_scan', 'nms_merge', 'pack_detections']
-PRICED = ('select_scan', 'score_hist', 'select_emit', 'assign_anchor', 'assign_fcos', 'nms_segments', 'select_finalize')
+           'select_refine', 'select_emit', 'select_finalize', 'select_direct_stats', 'select_direct', 'nms_segments', 'nms_scan', 'nms_merge', 'pack_detections']
+PRICED = ('select_scan', 'score_hist', 'select_emit', 'assign_anchor', 'assign_fcos', 'nms_segments', 'select_finalize',
+          'select_direct_stats', 'select_direct')
 
 
 def parse_args(argv=None):
@@ -351,6 +352,7 @@ def price(wl, m, world, steps):
         'assign_anchor': B * (48.0 * P + 24.0 * G_mean), 'assign_fcos': B * (52.0 * P + 24.0 * G_mean),
         'nms_segments': B * (28.0 * n_cand + 8.0 * n_keep),
         'select_finalize': B * (28.0 * n_cand + 32.0 * n_cand),
+        'select_direct_stats': score_bytes, 'select_direct': score_bytes + B * (28.0 * n_cand + 32.0 * n_cand),
     }
     achieved = alg_bytes[dom] / (m['dom_us'] * 1e-6) / 1e9
     roofline = dict(kernel=dom, bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',

@@ -52,10 +52,8 @@ __global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
     const float4 *__restrict__ gt_boxes, const int64_t *__restrict__ gt_labels,
     const int32_t *__restrict__ gt_off, int B, int imgs_per_block, float thr_lo, float thr_hi,
     float4 *__restrict__ locs, int64_t *__restrict__ labels, int64_t *__restrict__ matched,
-    unsigned long long *__restrict__ colbest, unsigned int *__restrict__ arrived, int total_gt,
-    int64_t *__restrict__ best_anchor) {
+    unsigned long long *__restrict__ colbest) {
     __shared__ float4 s_xyxy[GCHUNK];
-    __shared__ unsigned int s_last;
     __shared__ float s_area[GCHUNK];
     __shared__ float2 s_xy[GCHUNK];                 // YOLO: raw GT top-left
     __shared__ unsigned long long s_col[GCHUNK];
@@ -209,34 +207,9 @@ __global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
             labels[o] = (best[m] < thr_lo) ? 0 : ((best[m] < thr_hi) ? -1 : lbl);
         }
     }
-    // The workgroup that finishes last relabels the best anchor of every GT: by then every per-GT arg-max is final.
-    // (`max_ious[best_ids] = thr`, src/models/ssd300.py:258.  The anchor keeps the label of its OWN arg-max GT: the
-    // reference's "assign GT j" loop writes into a temporary, ssd300.py:256-257.)
-    if (total_gt <= 0 || arrived == nullptr) return;
-    __threadfence();                                   // this workgroup's labels, matched and atomics are out
-    __syncthreads();
-    if (tid == 0) s_last = atomicAdd(arrived, 1u) == gridDim.x * gridDim.y - 1u ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    for (int t = tid; t < total_gt; t += ASSIGN_BLOCK) {
-        int lo = 0, hi = B;                      // largest b with gt_off[b] <= t
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (gt_off[mid] <= t) lo = mid; else hi = mid;
-        }
-        const int b = lo;
-        const unsigned long long k = __hip_atomic_load(&colbest[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned pbest = (k == 0ull) ? 0u : (0xffffffffu - (unsigned)(k & 0xffffffffull));
-        if (best_anchor) best_anchor[t] = (int64_t)pbest;
-        const size_t o = (size_t)b * P + pbest;
-        const int64_t mt = __hip_atomic_load(&matched[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        labels[o] = (thr_hi < thr_lo) ? 0 : gt_labels[gt_off[b] + mt];
-    }
 }
 
-// Large grids: the same relabelling as a kernel of its own (a device-wide fence at the end of thousands of
-// workgroups costs more than a launch).  The best anchor of every GT is labelled as if its max IoU were thr_hi
+// The best anchor of every GT is labelled as if its max IoU were thr_hi
 // (`max_ious[best_ids] = thr`, src/models/ssd300.py:258).  It keeps the label
 // of its own arg-max GT: the reference's "assign GT j" loop writes into a
 // temporary (ssd300.py:256-257).
@@ -339,36 +312,30 @@ extern "C" size_t detbox_assign_anchor_workspace_bytes(int64_t total_gt) {
 
 namespace {
 
-// Shared by the two entry points: `colbest` holds one 64-bit slot per GT box and one more behind them (cleared here,
-// on the stream).
+// Shared by the two entry points: `colbest` holds one 64-bit slot per GT box (cleared here, on the stream).
 int assign_anchor_run(int mode, const float *anchors, int64_t P,
                       const float *gt_boxes, const int64_t *gt_labels, const int32_t *gt_offsets,
                       int64_t B, int64_t total_gt, float thr_lo, float thr_hi,
                       float *target_locs, int64_t *target_labels, int64_t *matched,
                       int64_t *best_anchor, unsigned long long *colbest, hipStream_t s) {
-    // one memset clears the per-GT slots and, right behind them, the counter of finished workgroups
-    unsigned int *arrived = reinterpret_cast<unsigned int *>(colbest + total_gt);
-    if (total_gt > 0) DETBOX_HIP(hipMemsetAsync(colbest, 0, (size_t)(total_gt + 1) * sizeof(unsigned long long), s));
+    if (total_gt > 0) DETBOX_HIP(hipMemsetAsync(colbest, 0, (size_t)total_gt * sizeof(unsigned long long), s));
     // four anchors per thread once that still leaves about four workgroups per CU (33 against 44 us on 16 x 120087 anchors)
     const int apt = (P * B >= (int64_t)4 * ASSIGN_BLOCK * 1024) ? 4 : 1;
     const int64_t tiles = (P + ASSIGN_BLOCK * apt - 1) / (ASSIGN_BLOCK * apt);
     const int ipb = pick_imgs_per_block(tiles, B);
     dim3 grid((unsigned)tiles, (unsigned)((B + ipb - 1) / ipb));
-    // small grids relabel the best anchors in the last workgroup to finish; large ones in a second launch
-    const bool fused = (int64_t)grid.x * grid.y <= 1024;
     {
         ProfScope ps("assign_anchor", s);
 #define DETBOX_ASSIGN(MODE, APT)                                                                                   \
     assign_anchor_kernel<MODE, APT><<<grid, dim3(ASSIGN_BLOCK), 0, s>>>(                                           \
         anchors, (int)P, reinterpret_cast<const float4 *>(gt_boxes), gt_labels, gt_offsets, (int)B, ipb, thr_lo,   \
-        thr_hi, reinterpret_cast<float4 *>(target_locs), target_labels, matched, colbest, fused ? arrived : nullptr, \
-        (int)total_gt, best_anchor)
+        thr_hi, reinterpret_cast<float4 *>(target_locs), target_labels, matched, colbest)
         if (mode == DETBOX_ASSIGN_CXCYWH) { if (apt == 4) DETBOX_ASSIGN(DETBOX_ASSIGN_CXCYWH, 4); else DETBOX_ASSIGN(DETBOX_ASSIGN_CXCYWH, 1); }
         else { if (apt == 4) DETBOX_ASSIGN(DETBOX_ASSIGN_YOLO, 4); else DETBOX_ASSIGN(DETBOX_ASSIGN_YOLO, 1); }
 #undef DETBOX_ASSIGN
         DETBOX_LAUNCH_CHECK();
     }
-    if (total_gt > 0 && !fused) {
+    if (total_gt > 0) {
         ProfScope ps("assign_fixup", s);
         assign_fixup_kernel<<<dim3((unsigned)((total_gt + 255) / 256)), dim3(256), 0, s>>>(
             colbest, gt_offsets, (int)B, (int)total_gt, (int)P, gt_labels, matched, thr_lo, thr_hi, target_labels,
@@ -416,7 +383,7 @@ extern "C" int detbox_assign_anchor(int mode, const float *anchors, int64_t P,
 // The per-GT arg-max slots live in a device array of this library instead of a caller workspace.  Every GPU the
 // library runs on holds its own copy at its own address; the address is looked up once per device (with that
 // device current) and kept.  Host code only ever uses that looked-up pointer.
-static __device__ __align__(256) unsigned long long scratch[DETBOX_ASSIGN_NOALLOC_MAX_GT + 1];      // + the counter of finished workgroups
+static __device__ __align__(256) unsigned long long scratch[DETBOX_ASSIGN_NOALLOC_MAX_GT];
 
 namespace {
 constexpr int MAX_DEVICES = 64;

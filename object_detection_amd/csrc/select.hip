@@ -1120,6 +1120,206 @@ __global__ __launch_bounds__(BLK) void select_finalize_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Direct path for small problems (P <= DIRECT_MAX_P anchors, a few million scores in all): two kernels
+// instead of the dozen of the streaming path, whose fixed launch chain is what such a call would spend
+// its time on.
+//   direct_stats   one streaming pass (the same sub-tile machinery, hence the same score bits): the activated
+//                  scores of the selected classes, written class-major so that a class's column is contiguous,
+//                  and per (image, class) the number of scores above the threshold, which fixes the class
+//                  segments of the output;
+//   direct_select  one workgroup per (image, class): the class's P scores go into LDS as ordered keys, the
+//                  top_k-th largest key is found by an exact 8-bit radix select (ties at the cut go to the
+//                  lower anchor), the winners are ranked in anchor order by wave-local ballots, decoded and
+//                  written.
+// Exact for any input: no sampling, no capacities, no fallback.
+// ---------------------------------------------------------------------------------------------
+
+constexpr int DIRECT_MAX_P = 16384;
+constexpr long long DIRECT_MAX_SCORES = 1ll << 23;
+
+template <int ACT, int EPT>
+__global__ __launch_bounds__(SCAN_BLOCK) void direct_stats_kernel(const float *__restrict__ in,
+                                                                  const float *__restrict__ extra, SelParams sp,
+                                                                  float *__restrict__ colscores,
+                                                                  uint32_t *__restrict__ npos) {
+    extern __shared__ float s_dynf[];
+    __shared__ uint32_t s_cnt[MAX_SEL_CLASSES];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int cb = sp.cb, C = sp.C;
+    const int r = tid / LPR, sub = tid % LPR;
+    const long long sub0 = (long long)blockIdx.x * sp.subs_per_block;
+    const long long sub1 = min((long long)sp.n_sub, sub0 + sp.subs_per_block);
+    if (tid < MAX_SEL_CLASSES) s_cnt[tid] = 0u;
+    __syncthreads();
+    uint32_t cnt[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) cnt[i] = 0u;
+    const float thr = sp.thr;
+    float *cs = colscores + (size_t)b * sp.Cs * sp.P;
+    const size_t P = (size_t)sp.P;
+    for_each_subtile<ACT, EPT>(in, extra, b, sp.P, C, sp.total_floats, sub0, sub1, 1, s_dynf, sp.tile_floats,
+                               [&](float (&x)[EPT], bool valid, int r0, const RowCtx &) {
+                                   if (!valid) return;
+                                   float *o = cs + r0 + r;
+#pragma unroll
+                                   for (int i = 0; i < EPT; ++i) {
+                                       const int c = sub + LPR * i;
+                                       if (c >= cb && c < C) {
+                                           o[(size_t)(c - cb) * P] = x[i];
+                                           if (x[i] > thr) ++cnt[i];
+                                       }
+                                   }
+                               },
+                               [](long long) {});
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int c = sub + LPR * i;
+        if (cnt[i] && c >= cb && c < C) atomicAdd(&s_cnt[c - cb], cnt[i]);
+    }
+    __syncthreads();
+    if (tid < sp.Cs && s_cnt[tid]) atomicAdd(&npos[(size_t)b * sp.Cs + tid], s_cnt[tid]);
+}
+
+template <int DECODE>
+__global__ __launch_bounds__(256) void direct_select_kernel(
+    const float *__restrict__ colscores, SelParams sp, const uint32_t *__restrict__ npos,
+    const float4 *__restrict__ locs, const float *__restrict__ anchors, int class_id_offset,
+    float4 *__restrict__ out_boxes, float *__restrict__ out_scores, int64_t *__restrict__ out_cls,
+    int32_t *__restrict__ seg_off, int32_t *__restrict__ counts) {
+    extern __shared__ uint32_t s_d[];                  // [P] ordered score keys above the threshold, 0 = not a candidate
+    __shared__ __align__(16) uint32_t s_h[256];
+    __shared__ uint32_t s_h16[16 * 257];
+    __shared__ uint32_t s_pref, s_need, s_row0;
+    __shared__ uint32_t s_wgt[4], s_weq[4];
+    const int ci = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = sp.P, Cs = sp.Cs;
+    const uint32_t k = (uint32_t)sp.top_k;
+    const uint32_t *np = npos + (size_t)b * Cs;
+    // class segments of the image: class c contributes min(top_k, scores above the threshold) rows
+    __shared__ uint32_t s_n[MAX_SEL_CLASSES];
+    if (tid < Cs) s_n[tid] = min(k, np[tid]);              // all the counts in one round of loads
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0u;
+        for (int t = 0; t < ci; ++t) acc += s_n[t];
+        s_row0 = acc;
+        s_pref = 0u;
+        if (ci == 0) {
+            int32_t *so = seg_off + (size_t)b * (Cs + 1);
+            for (int t = 0; t < Cs; ++t) { so[t] = (int32_t)acc; acc += s_n[t]; }
+            so[Cs] = (int32_t)acc;
+            counts[b] = (int32_t)acc;
+        }
+    }
+    __syncthreads();
+    const uint32_t n_pos = np[ci];
+    const uint32_t n_sel = min(k, n_pos);
+    if (n_sel == 0u) return;                           // block-uniform
+    // the class's scores as keys (eight loads in flight per thread: the column is read once and the read is all latency)
+    const int c = ci + sp.cb;
+    const float *col = colscores + ((size_t)b * Cs + ci) * P;
+    for (int base = tid; base < P; base += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = base + u * 256;
+            v[u] = p < P ? col[p] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = base + u * 256;
+            if (p < P) s_d[p] = v[u] > sp.thr ? okey(v[u]) - sp.key_thr : 0u;
+        }
+    }
+    __syncthreads();
+    // the top_k-th largest key d* and how many keys equal to it are taken (lowest anchors first)
+    uint32_t dstar = 0u, need_eq = 0u;
+    if (n_pos > k) {
+        if (tid == 0) s_need = k;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            // scores of one class crowd into a few digits: sixteen copies of the histogram (one per lane modulo 16,
+            // 257 words apart so that equal digits fall into different banks) keep the LDS atomics from serialising
+            for (int i = tid; i < 16 * 257; i += 256) s_h16[i] = 0u;
+            __syncthreads();
+            const uint32_t pref = s_pref;
+            uint32_t *mine = s_h16 + (lane & 15) * 257;
+            for (int p = tid; p < P; p += 256) {
+                const uint32_t d = s_d[p];
+                if (d && (shift == 24 || (d >> (shift + 8)) == (pref >> (shift + 8)))) atomicAdd(&mine[(d >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            {
+                uint32_t acc = 0u;
+#pragma unroll
+                for (int cpy = 0; cpy < 16; ++cpy) acc += s_h16[cpy * 257 + tid];
+                s_h[tid] = acc;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const uint4 q = reinterpret_cast<const uint4 *>(s_h)[lane];
+                const uint32_t t = q.x + q.y + q.z + q.w;
+                const uint32_t suf = suffix_scan64(t, lane);
+                uint32_t digit, above, nd;
+                find_kth_bin(q, suf, t, lane, s_need, digit, above, nd);
+                if (lane == 0) { s_pref = pref | (digit << shift); s_need -= above; }
+            }
+            __syncthreads();
+        }
+        dstar = s_pref;
+        need_eq = s_need;                                 // >= 1: the key d* itself is among the top_k
+    }
+    // wave w walks anchors [w*Q, (w+1)*Q): first the totals per wave, then ranks and output
+    const int Q = ((P + 255) / 256) * 64;
+    const int p_lo = wv * Q, p_hi = min(P, p_lo + Q);
+    uint32_t gt = 0u, eq = 0u;
+    for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
+        const int p = p0 + lane;
+        const uint32_t d = p < p_hi ? s_d[p] : 0u;
+        gt += (uint32_t)__popcll(__ballot(d > dstar));
+        eq += (uint32_t)__popcll(__ballot(d == dstar && d != 0u));
+    }
+    if (lane == 0) { s_wgt[wv] = gt; s_weq[wv] = eq; }
+    __syncthreads();
+    uint32_t eq_before = 0u, sel_before = 0u;
+    for (int w = 0; w < wv; ++w) {
+        const uint32_t e = s_weq[w];
+        const uint32_t take = eq_before >= need_eq ? 0u : min(e, need_eq - eq_before);
+        sel_before += s_wgt[w] + take;
+        eq_before += e;
+    }
+    // winners into LDS at their rank first; the decode and the output rows then go out in one dense pass (the gathers
+    // of a sparse, lane-masked loop would each wait out their own latency)
+    unsigned long long *s_win = reinterpret_cast<unsigned long long *>(s_d + ((P + 1) & ~1));
+    for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
+        const int p = p0 + lane;
+        const uint32_t d = p < p_hi ? s_d[p] : 0u;
+        const bool is_eq = d == dstar && d != 0u;
+        const unsigned long long em = __ballot(is_eq);
+        const uint32_t my_eq = eq_before + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+        const bool sel = d > dstar || (is_eq && my_eq < need_eq);
+        const unsigned long long sm = __ballot(sel);
+        if (sel) {
+            const uint32_t rank = sel_before + __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
+            if (rank < n_sel) s_win[rank] = ((unsigned long long)d << 32) | (uint32_t)p;
+        }
+        eq_before += (uint32_t)__popcll(em);
+        sel_before += (uint32_t)__popcll(sm);
+    }
+    __syncthreads();
+    const size_t row0 = (size_t)b * ((size_t)Cs * sp.top_k) + s_row0;
+    for (uint32_t rank = (uint32_t)tid; rank < n_sel; rank += 256u) {
+        const unsigned long long w = s_win[rank];
+        const uint32_t p = (uint32_t)w, d = (uint32_t)(w >> 32);
+        const float4 l = locs[(size_t)b * P + p];
+        out_boxes[row0 + rank] = decode_box<DECODE>(anchors, l, p);
+        out_scores[row0 + rank] = __uint_as_float(bits_from_okey(sp.key_thr + d));
+        out_cls[row0 + rank] = (int64_t)(c + class_id_offset);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------
 
@@ -1216,9 +1416,21 @@ SelPlan make_plan(int64_t B, int64_t P, int64_t C, int64_t Cs, int top_k) {
 
 struct SelLayout { size_t hist, cnt, flag, img_ovf, blk_cnt, rules, staging, samp, blk_list, scores, total; };
 
+bool use_direct(int64_t B, int64_t P, int64_t C) { return P <= DIRECT_MAX_P && B * P * C <= DIRECT_MAX_SCORES; }
+
+// direct path: the activated scores class-major [B, Cs, P], then the per-(image, class) counts [B*Cs]
+size_t direct_bytes(int64_t B, int64_t P, int64_t Cs) {
+    return align_up((size_t)B * Cs * P * sizeof(float), 256) + align_up((size_t)B * Cs * sizeof(uint32_t), 256);
+}
+
 SelLayout layout(int64_t B, int64_t P, int64_t C, int64_t Cs, const SelPlan &pl, int act) {
     SelLayout L;
     size_t off = 0;
+    if (use_direct(B, P, C)) {
+        std::memset(&L, 0, sizeof(L));
+        L.total = direct_bytes(B, P, Cs);
+        return L;
+    }
     L.hist = off; off = align_up(off + (size_t)B * Cs * NB * sizeof(uint32_t), 256);
     L.cnt = off; off = align_up(off + (size_t)B * Cs * sizeof(uint32_t), 256);
     L.flag = off; off = align_up(off + sizeof(uint32_t), 256);
@@ -1349,6 +1561,28 @@ int dispatch_act_ept(int act, int ept, const A &a) {
 #undef DETBOX_ROW
 }
 
+struct DirectArgs {
+    const float *in, *extra;
+    SelParams sp;
+    int64_t B;
+    float *colscores;
+    uint32_t *npos;
+    hipStream_t s;
+};
+
+template <int ACT, int EPT>
+struct LaunchDirectStats {
+    static int run(const DirectArgs &a) {
+        const size_t lds = 2 * (size_t)a.sp.tile_floats * 4;
+        if (int rc = set_lds(direct_stats_kernel<ACT, EPT>, lds)) return rc;
+        ProfScope ps("select_direct_stats", a.s);
+        direct_stats_kernel<ACT, EPT><<<dim3((unsigned)a.sp.scan_gx, (unsigned)a.B), dim3(SCAN_BLOCK), lds, a.s>>>(
+            a.in, a.extra, a.sp, a.colscores, a.npos);
+        DETBOX_LAUNCH_CHECK();
+        return DETBOX_OK;
+    }
+};
+
 int check_act(int activation, const float *extra) {
     DETBOX_CHECK_ARG(activation >= ACT_NONE && activation <= ACT_SIGMOID_SIGMOID, "unknown activation");
     DETBOX_CHECK_ARG(activation == ACT_NONE || activation == ACT_SOFTMAX || extra, "this activation needs `extra`");
@@ -1469,6 +1703,34 @@ extern "C" int detbox_select_decode(int decode_mode, int activation, const float
     sp.tile_floats = tile_floats_for(C);
     sp.total_floats = (long long)B * P * C;
 
+    if (use_direct(B, P, C)) {
+        float *colscores = reinterpret_cast<float *>(ws);
+        uint32_t *npos = reinterpret_cast<uint32_t *>(ws + align_up((size_t)B * Cs * P * sizeof(float), 256));
+        DETBOX_HIP(hipMemsetAsync(npos, 0, (size_t)B * Cs * sizeof(uint32_t), s));
+        // enough workgroups to fill the chip, at least one sub-tile each
+        int64_t spb = (B * sp.n_sub + 1023) / 1024;
+        sp.subs_per_block = (int)(spb < 1 ? 1 : spb);
+        sp.scan_gx = (sp.n_sub + sp.subs_per_block - 1) / sp.subs_per_block;
+        DirectArgs a;
+        a.in = scores; a.extra = extra; a.sp = sp; a.B = B; a.colscores = colscores; a.npos = npos; a.s = s;
+        if (int rc = dispatch_act_ept<LaunchDirectStats>(activation, ept_for(C), a)) return rc;
+        const size_t lds = (size_t)((P + 1) & ~1ll) * 4 + (size_t)top_k * 8;      // keys, then the winners in rank order
+        const float4 *l4 = reinterpret_cast<const float4 *>(locs);
+        float4 *ob = reinterpret_cast<float4 *>(out_boxes);
+        ProfScope ps("select_direct", s);
+#define DETBOX_DIRECT(D)                                                                                          \
+    {                                                                                                             \
+        if (int rc2 = set_lds(direct_select_kernel<D>, lds)) return rc2;                                          \
+        direct_select_kernel<D><<<dim3((unsigned)Cs, (unsigned)B), dim3(256), lds, s>>>(                          \
+            colscores, sp, npos, l4, anchors, class_id_offset, ob, out_scores, out_class_ids, out_seg_offsets, out_counts); \
+    }
+        if (decode_mode == DETBOX_DECODE_CXCYWH) DETBOX_DIRECT(DETBOX_DECODE_CXCYWH)
+        else if (decode_mode == DETBOX_DECODE_YOLO) DETBOX_DIRECT(DETBOX_DECODE_YOLO)
+        else DETBOX_DIRECT(DETBOX_DECODE_FCOS)
+#undef DETBOX_DIRECT
+        DETBOX_LAUNCH_CHECK();
+        return DETBOX_OK;
+    }
     {
         FastArgs a;
         a.in = scores; a.extra = extra; a.sp = sp; a.B = B; a.flag = flag; a.cnt = cnt; a.img_ovf = img_ovf; a.hist = ghist;

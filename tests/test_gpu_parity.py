@@ -485,6 +485,24 @@ def test_select_ties_and_degenerate_inputs(D, oracle, dev):
     check_select((pb, ps, pc), oracle_select(O, s[:1], locs[:1], anchors, 0, 1, 0, 0.01, 50, fast=False))
 
 
+def test_select_every_path_by_size(D, oracle, dev):
+    """The same small table through the three selection paths: the direct two-kernel path (few scores in all), the
+    exact histogram path (P < 4096 but too many scores in the batch for the direct path) and, with P >= 4096 and a big
+    batch, the sampled streaming path.  All against the oracle, with massive ties in one image."""
+    O = oracle
+    g = torch.Generator().manual_seed(41)
+    for fk, B, C in (([16, 8, 4, 2, 1], 2, 9), ([16, 8, 4, 2, 1], 400, 9), ([24, 12, 6, 3, 2], 180, 9)):
+        anchors = D.anchors.retinanet_prior_boxes(fk)            # 3069 / 6921 anchors
+        P = anchors.shape[0]
+        s = torch.rand(B, P, C, generator=g)
+        s[0] = (s[0] * 6).round() / 6
+        locs = torch.randn(B, P, 4, generator=g)
+        _, pb, ps, pc = hip_select(D, dev, s, locs, anchors, D.ops.DECODE_CXCYWH, 1, 0, 0.2, 150)
+        pick = [0, 1, B - 1]
+        want = oracle_select(O, s[pick], locs[pick], anchors, 0, 1, 0, 0.2, 150)
+        check_select(([pb[i] for i in pick], [ps[i] for i in pick], [pc[i] for i in pick]), want)
+
+
 def test_select_at_the_documented_limits(D, oracle, dev):
     """Widest class counts (C = 129 with 128 selected classes; C = 200 selecting the upper 100), largest
     top_k (4096) on a sampled-path size, and a fused activation at C = 200."""
