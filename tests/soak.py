@@ -24,6 +24,7 @@ from oracle import boxops_oracle as O  # noqa: E402
 dev = torch.device('cuda', 0)
 BUDGET = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+ONLY = sys.argv[3].split(',') if len(sys.argv) > 3 else None      # category names, default all
 
 
 def close(a, b, rtol=1e-5):
@@ -168,9 +169,71 @@ def soak_assign_large(g):
     return ok, dict(kind='assign_large', B=B, P=P)
 
 
+E2E = dict(images=0, candidates=0, selection_diff=0, kept=0, images_with_keep_diff=0, keep_differing=0, unexplained=0)
+E2E_WHY = {}
+
+
+def soak_from_logits(g):
+    """The shipped path from raw logits (fused activation, HIP decode) against the reference arithmetic on the CPU
+    (torch's own soft-max / sigmoid, the oracle's decode and NMS): counts every difference and requires each one to
+    sit on a rounding boundary (tests/e2e_compare.py).  The totals are printed at the end, per 10^6 candidates."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import e2e_compare as E
+    fam = int(torch.randint(0, 3, (1,), generator=g))
+    k = [100, 200, 400][int(torch.randint(0, 3, (1,), generator=g))]
+    thr = [0.01, 0.05][int(torch.randint(0, 2, (1,), generator=g))]
+    B = 2
+    if fam == 0:
+        m, C = D.SSD300(20), 21
+    elif fam == 1:
+        m, C = D.RetinaNet(20, [40, 20, 10, 5, 3]), 21
+    else:
+        m, C = D.FCOS(20, [64, 32, 16, 8, 4]), 21
+    anchors = m._anchors_for_decode()
+    P = anchors.shape[0]
+    scale = float(torch.rand(1, generator=g) * 1.5 + 0.5)
+    locs = torch.randn(B, P, 4, generator=g) + (3.0 if fam == 2 else 0.0)
+    confs = torch.randn(B, P, C, generator=g) * scale
+    confs[1, :, 0] += float(torch.rand(1, generator=g) * 6 + 2)
+    ext = torch.randn(B, P, generator=g) if fam == 2 else None
+    outs_cpu = (locs, confs) + ((ext,) if ext is not None else ())
+    if fam == 2:
+        ref_scores = torch.softmax(confs, -1) * ext.sigmoid()[..., None]
+        rb, rs, rc = O.pre_predict_fcos(locs, confs, ext, anchors, thr, k, fast=True)
+    else:
+        ref_scores = torch.softmax(confs, -1)
+        rb, rs, rc = O.pre_predict_softmax(locs, confs, anchors, thr, k, fast=True)
+    outs = tuple(o.to(dev) for o in outs_cpu)
+    pb, ps, pc = m.pre_predict(tuple(o.clone() for o in outs), thr, k)
+    c = m.candidates(tuple(o.clone() for o in outs), thr, k)
+    keep, kc = D.ops.nms_candidates(c, 0.45)
+    _, hip_scores = m._activate(tuple(o.clone() for o in outs))
+    hip_scores = hip_scores.cpu()
+    ok = True
+    for b in range(B):
+        rk = O.batched_nms(rb[b], rs[b], rc[b], 0.45)
+        hk = keep[b, :int(kc[b])].cpu()
+        rep = E.compare_image(ref_scores[b], hip_scores[b], dict(boxes=rb[b], scores=rs[b], keep=rk),
+                              dict(boxes=pb[b], scores=ps[b], keep=hk), 1, thr, k, 0.45)
+        E2E['images'] += 1
+        E2E['candidates'] += rep['candidates_ref']
+        E2E['selection_diff'] += rep['selection_diff']
+        E2E['kept'] += rep['keep_ref']
+        E2E['images_with_keep_diff'] += 1 if rep['keep_differing'] else 0
+        E2E['keep_differing'] += rep['keep_differing']
+        E2E['unexplained'] += len(rep['unexplained'])
+        if rep['first_divergence']:
+            why = rep['first_divergence'].get('hip_why') or rep['first_divergence'].get('ref_why')
+            E2E_WHY[why] = E2E_WHY.get(why, 0) + 1
+        ok = ok and not rep['unexplained']
+    return ok, dict(kind='from_logits', fam=fam, k=k, thr=thr)
+
+
 def main():
     for name, fn in (('nms', soak_nms), ('select', soak_select), ('assign', soak_assign),
-                     ('select_many', soak_select_many), ('assign_large', soak_assign_large)):
+                     ('select_many', soak_select_many), ('assign_large', soak_assign_large), ('from_logits', soak_from_logits)):
+        if ONLY and name not in ONLY:
+            continue
         g = torch.Generator().manual_seed(SEED * 1000 + hash(name) % 997)
         t0, n = time.time(), 0
         last = t0
@@ -187,6 +250,11 @@ def main():
                 print(f'{name}: {n} cases ok', flush=True)
                 last = time.time()
         print(f'{name}: {n} cases ok in {time.time() - t0:.0f} s', flush=True)
+    if E2E['candidates']:
+        per = 1e6 / E2E['candidates']
+        print('from_logits totals:', E2E, f"-> per 10^6 candidates: {E2E['selection_diff'] * per:.1f} selection differences, "
+              f"{E2E['keep_differing'] * per:.1f} keep-list positions that differ; unexplained: {E2E['unexplained']}", flush=True)
+        print('from_logits first divergence of an image, by cause:', E2E_WHY, flush=True)
 
 
 if __name__ == '__main__':
