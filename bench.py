@@ -134,12 +134,21 @@ class Workload:
 
     def step(self, world):
         """The whole path once.  Returns device tensors; no host synchronisation for world == 1."""
+        extra = os.environ.get('DETBOX_BENCH_TWICE', '').split(',')     # measurement aid: marginal cost of one stage
         targets = self.assign()
+        if 'assign' in extra:
+            targets = self.assign()
         m = self.model
         c = m.candidates(self.outputs(), 0.01, self.top_k)      # activation fused into the selection pass
+        if 'select' in extra:
+            c = m.candidates(self.outputs(), 0.01, self.top_k)
         keep, kc = ops.nms_candidates(c, 0.45)
+        if 'nms' in extra:
+            keep, kc = ops.nms_candidates(c, 0.45)
         if world == 1:
             rows_ids, rows_vals, row_off = ops.pack_detections(c.boxes, c.scores, c.class_ids, keep, kc, self.ids, self.hw)
+            if 'pack' in extra:
+                rows_ids, rows_vals, row_off = ops.pack_detections(c.boxes, c.scores, c.class_ids, keep, kc, self.ids, self.hw)
         else:
             # the exchange step: this rank's detections as a compact message; the gather of the previous
             # batch's messages starts now, on a side stream, and overlaps this batch's kernels

@@ -1349,18 +1349,20 @@ int tile_floats_for(int64_t C) { return (int)(((SUB_ROWS * C + LPR * ept_for(C) 
 
 // Workgroups of the scan that are resident at once: LDS-limited, on every CU of the device.
 int64_t scan_resident_workgroups(int64_t C) {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        cus = n;
+    static int cus[64] = {0};                                     // per device; a racing first call writes the same value
+    static const int per_cu_cap = [] { const char *e = std::getenv("DETBOX_SCAN_PER_CU"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 8; }();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
     }
     const size_t lds = 2 * (size_t)tile_floats_for(C) * 4 + 16 + (size_t)(SCAN_BLOCK / 64) * SCAN_EBUF * 8;
     int64_t per_cu = (int64_t)((160 * 1024) / lds);
-    if (per_cu > 8) per_cu = 8;
+    if (per_cu > per_cu_cap) per_cu = per_cu_cap;
     if (per_cu < 1) per_cu = 1;
-    return per_cu * cus;
+    return per_cu * cus[dev];
 }
 
 SelPlan make_plan(int64_t B, int64_t P, int64_t C, int64_t Cs, int top_k) {
