@@ -269,7 +269,8 @@ int detbox_debug_stream_read(const float *in, int64_t n, float *out, int blocks,
  * on the current device since the last reset, collected while switched on (detbox_debug_nms_stats_enable, or the
  * environment variable DETBOX_NMS_STATS at load time; a few atomics per wave).  Synchronises the device. out8[0] segments, [1] segments redone by
  * the chunked algorithm because a pair queue overflowed, [2] pairs that passed the centre-distance filter,
- * [3] pairs with iou above the threshold, [4] queue drains; [5..7] unused. */
+ * [3] pairs with iou above the threshold, [4] queue drains; [5..7] clock cycles of each segment's first wave in the
+ * three phases (sort and records; all pairs; resolve and output), summed over segments. */
 int detbox_debug_nms_stats_enable(int on);
 int detbox_debug_nms_stats(uint64_t *out8, int reset);
 

@@ -777,6 +777,7 @@ __device__ inline bool nms_pairs_body(
     const float u_min = thr > 0.0f ? 1e-30f / thr : __builtin_inff();
 
     // ---- 1. sort
+    const long long t_begin = np.stats ? (long long)__builtin_readcyclecounter() : 0ll;
     int n2 = 2;
     while (n2 < n) n2 <<= 1;
     {
@@ -857,6 +858,7 @@ __device__ inline bool nms_pairs_body(
         cq[m] = c; nj[m] = rj;
     }
     __syncthreads();                                      // records visible; the sort exchange buffer is dead: queues may fill
+    const long long t_sorted = np.stats ? (long long)__builtin_readcyclecounter() : 0ll;
 
     // ---- 2b / 3. all pairs (i before j), wave-local queue
     uint32_t *q = s_queue + wv * QCAP;
@@ -979,6 +981,7 @@ __device__ inline bool nms_pairs_body(
     }
 
     // ---- 4. resolve in score order
+    const long long t_swept = np.stats ? (long long)__builtin_readcyclecounter() : 0ll;
     uint32_t nev[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) nev[w] = s_ne[w];
@@ -1042,6 +1045,11 @@ __device__ inline bool nms_pairs_body(
         const uint32_t rank = s_wprefix[i >> 6] + (uint32_t)__popcll(~rem & ((1ull << (i & 63)) - 1ull));
         const int p = seg0 + orig[m];
         kept[row0 + rank] = make_float2(__uint_as_float(okey_from_bits(__float_as_uint(scores[(size_t)b * np.stride + p] + 0.0f))), __int_as_float(p));
+    }
+    if (np.stats && tid == 0) {                            // cycles of wave 0 per phase: sort + records, all pairs, resolve + output
+        atomicAdd(&g_pair_stats[5], (unsigned long long)(t_sorted - t_begin));
+        atomicAdd(&g_pair_stats[6], (unsigned long long)(t_swept - t_sorted));
+        atomicAdd(&g_pair_stats[7], (unsigned long long)((long long)__builtin_readcyclecounter() - t_swept));
     }
     return true;
 }

