@@ -535,6 +535,20 @@ __global__ __launch_bounds__(BLK) void select_plan_kernel(const float *__restric
     if (tid == 0) rules[(size_t)b * sp.Cs + ci] = r;
 }
 
+// Inclusive prefix sum over the 64 lanes with data-parallel-primitive moves: shifts inside the rows of 16, then the row
+// totals are broadcast into the following rows.  Every lane of the wave must be active.
+__device__ inline uint32_t wave_inclusive_add(uint32_t v) {
+#define DETBOX_DPP_ADD(ctrl, rows) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, false)
+    DETBOX_DPP_ADD(0x111, 0xf);     // row_shr:1
+    DETBOX_DPP_ADD(0x112, 0xf);     // row_shr:2
+    DETBOX_DPP_ADD(0x114, 0xf);     // row_shr:4
+    DETBOX_DPP_ADD(0x118, 0xf);     // row_shr:8
+    DETBOX_DPP_ADD(0x142, 0xa);     // row_bcast:15 into rows 1 and 3
+    DETBOX_DPP_ADD(0x143, 0xc);     // row_bcast:31 into rows 2 and 3
+#undef DETBOX_DPP_ADD
+    return v;
+}
+
 // Staged candidate as the scan writes it: score key (32) | class slot (8) | anchor (24).
 __device__ inline unsigned long long pack_entry(uint32_t d, uint32_t ci, uint32_t p) {
     return ((unsigned long long)d << 32) | ((unsigned long long)ci << 24) | (unsigned long long)p;
@@ -591,27 +605,57 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
                     asm volatile("v_cmp_ge_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
                                  : "+v"(pm_lo) : "v"(x[i]), "v"(tlo[i]) : "vcc");
             }
-            unsigned long long pm = valid ? (((unsigned long long)pm_hi << 32) | pm_lo) : 0ull;
-            // round k appends the k-th candidate of every lane that still has one.  Entries go to the wave's buffer in
-            // LDS first: a global store inside the loop would be waited for at the sub-tile's barrier (the counter
-            // that tells the tile's DMA has landed counts stores as well), once per sub-tile; the buffer is flushed
-            // once per dozen sub-tiles instead.
-            unsigned long long has = __ballot(pm != 0ull);
             const uint32_t p = (uint32_t)(r0 + r);
-            while (has) {
-                if (ln + 64u > (uint32_t)SCAN_EBUF) flush();
-                if (pm) {
-                    const uint32_t slot = ln + __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0u));
-                    const int i = __ffsll((long long)pm) - 1;
-                    pm &= pm - 1ull;
-                    const float sc = rescore<ACT>(ctx, i);               // same arithmetic as x[i], bit for bit
-                    ebuf[slot] = pack_entry(okey(sc) - key_thr, (uint32_t)(sub + LPR * i - cb), p);
+            if (!valid) { pm_lo = 0u; pm_hi = 0u; }
+            // Every lane's entries get consecutive slots of the wave's LDS buffer: popcount per lane, prefix sum over the wave
+            // (the order of the entries inside the list is irrelevant), then each lane writes its own entries.  A global store
+            // inside the loop would be waited for at the sub-tile's barrier (the counter that tells the tile's DMA has landed
+            // counts stores as well), once per sub-tile; the buffer is flushed once per dozen sub-tiles instead.
+            uint32_t cnt = (uint32_t)__popc(pm_lo) + (EPT > 32 ? (uint32_t)__popc(pm_hi) : 0u);
+            if (__ballot(cnt != 0u) != 0ull) {
+                const uint32_t inc = wave_inclusive_add(cnt);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                if (total <= (uint32_t)SCAN_EBUF) {
+                    if (ln + total > (uint32_t)SCAN_EBUF) flush();
+                    uint32_t slot = ln + inc - cnt;
+                    auto put = [&](int i) {
+                        const float sc = rescore<ACT>(ctx, i);               // same arithmetic as x[i], bit for bit
+                        ebuf[slot++] = pack_entry(okey(sc) - key_thr, (uint32_t)(sub + LPR * i - cb), p);
+                    };
+                    while (pm_lo) {
+                        const int i = __ffs((int)pm_lo) - 1;
+                        pm_lo &= pm_lo - 1u;
+                        put(i);
+                    }
+                    if (EPT > 32)
+                        while (pm_hi) {
+                            const int i = __ffs((int)pm_hi) - 1;
+                            pm_hi &= pm_hi - 1u;
+                            put(32 + i);
+                        }
+                    ln += total;
+                } else {
+                    // more entries than the buffer holds (nearly every score of the sub-tile is staged): round k appends the
+                    // k-th entry of every lane that still has one
+                    unsigned long long pm = ((unsigned long long)pm_hi << 32) | pm_lo;
+                    unsigned long long has = __ballot(pm != 0ull);
+                    while (has) {
+                        if (ln + 64u > (uint32_t)SCAN_EBUF) flush();
+                        if (pm) {
+                            const uint32_t slot = ln + __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0u));
+                            const int i = __ffsll((long long)pm) - 1;
+                            pm &= pm - 1ull;
+                            const float sc = rescore<ACT>(ctx, i);
+                            ebuf[slot] = pack_entry(okey(sc) - key_thr, (uint32_t)(sub + LPR * i - cb), p);
+                        }
+                        ln += (uint32_t)__popcll(has);
+                        has = __ballot(pm != 0ull);
+                    }
                 }
-                ln += (uint32_t)__popcll(has);
-                has = __ballot(pm != 0ull);
             }
         },
-        [](long long) {});
+        // behind the barrier: the stores have the whole next sub-tile to complete before a barrier waits for them
+        [&](long long) { if (ln >= (uint32_t)SCAN_EBUF / 2u) flush(); });
     flush();
     if ((tid & 63) == 0) {
         blk_cnt[blk * 4 + wv] = wn < wcap ? wn : wcap;
