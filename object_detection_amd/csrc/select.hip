@@ -1389,10 +1389,11 @@ int tile_floats_for(int64_t C) { return (int)(((SUB_ROWS * C + LPR * ept_for(C) 
 // Workgroups of the scan that are resident at once: LDS-limited, on every CU of the device.
 int64_t scan_resident_workgroups(int64_t C) {
     static int cus[64] = {0};                                     // per device; a racing first call writes the same value
-    // Two workgroups per CU already keep the DMA pipeline at its rate (a third adds 1 % to the scan on its own); the LDS
-    // left over lets workgroups of another batch's kernels (NMS, on another stream) run beside the scan: 1.5 % more
-    // images/s with three batches in flight.
-    static const int per_cu_cap = [] { const char *e = std::getenv("DETBOX_SCAN_PER_CU"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 2; }();
+    // One sub-tile per workgroup is in flight, and about 40 KB in flight per CU keep the DMA pipeline at its rate (two
+    // workgroups at C = 81, eight at C = 21; a third workgroup at C = 81 adds 1 % to the scan on its own).  The LDS left
+    // over lets workgroups of another batch's kernels (NMS, on another stream) run beside the scan: 1.5 % more
+    // images/s with three batches in flight.  DETBOX_SCAN_PER_CU overrides.
+    static const int per_cu_env = [] { const char *e = std::getenv("DETBOX_SCAN_PER_CU"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 0; }();
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (cus[dev] == 0) {
@@ -1400,9 +1401,12 @@ int64_t scan_resident_workgroups(int64_t C) {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         cus[dev] = n;
     }
-    const size_t lds = 2 * (size_t)tile_floats_for(C) * 4 + 16 + (size_t)(SCAN_BLOCK / 64) * SCAN_EBUF * 8;
+    const size_t tile = (size_t)tile_floats_for(C) * 4;
+    const size_t lds = 2 * tile + 16 + (size_t)(SCAN_BLOCK / 64) * SCAN_EBUF * 8;
     int64_t per_cu = (int64_t)((160 * 1024) / lds);
-    if (per_cu > per_cu_cap) per_cu = per_cu_cap;
+    const int64_t want = per_cu_env ? per_cu_env : (int64_t)((40 * 1024 + tile - 1) / tile);
+    if (per_cu > want) per_cu = want;
+    if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
     return per_cu * cus[dev];
 }
