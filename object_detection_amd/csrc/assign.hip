@@ -44,7 +44,7 @@ __device__ inline float wave_max(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// APT anchors per thread (anchor m of a thread is 256 anchors after anchor m-1): with several, the staging of
+// APT anchors per thread: with several, the staging of
 // an image's GT boxes, the barriers and the per-GT atomics are shared by APT * 256 anchors.
 template <int MODE, int APT>
 __global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
@@ -61,7 +61,10 @@ __global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
     __shared__ int64_t s_lbl[GCHUNK];
 
     const int tid = threadIdx.x;
-    const int p0 = blockIdx.x * (ASSIGN_BLOCK * APT) + tid;
+    // A wave owns APT * 64 consecutive anchors (anchor m of a lane is 64 after anchor m - 1): every access is a
+    // contiguous kilobyte, and the bounds of the wave's anchors -- what lets it step over GT boxes -- stay tight.
+    constexpr int MSTRIDE = 64;
+    const int p0 = blockIdx.x * (ASSIGN_BLOCK * APT) + (tid >> 6) * (64 * APT) + (tid & 63);
 
     // anchors in registers: raw (for encoding), xyxy + area (for IoU)
     float a0[APT], a1[APT], a2[APT], a3[APT], grid[APT];
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
     float bx1 = inf, by1 = inf, bx2 = -inf, by2 = -inf;
 #pragma unroll
     for (int m = 0; m < APT; ++m) {
-        const int p = p0 + m * ASSIGN_BLOCK;
+        const int p = p0 + m * MSTRIDE;
         valid[m] = p < P;
         a0[m] = 0.f; a1[m] = 0.f; a2[m] = 1.f; a3[m] = 1.f; grid[m] = 1.f;
         if (valid[m]) {
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
 #pragma unroll
             for (int m = 0; m < APT; ++m)
                 if (valid[m]) {
-                    const size_t o = o0 + m * ASSIGN_BLOCK;
+                    const size_t o = o0 + m * MSTRIDE;
                     locs[o] = make_float4(0.f, 0.f, 0.f, 0.f); labels[o] = 0; matched[o] = -1;
                 }
             continue;
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
                 if (__ballot(vmax > 0.0f) != 0ull) {           // wave-uniform
                     const float wm = wave_max(vmax);
                     if (vmax == wm) {                          // several lanes only on exact ties: the lowest anchor wins the max
-                        const unsigned p = (unsigned)(p0 + mmax * ASSIGN_BLOCK);
+                        const unsigned p = (unsigned)(p0 + mmax * MSTRIDE);
                         atomicMax(&s_col[j], ((unsigned long long)__float_as_uint(wm) << 32) | (unsigned long long)(0xffffffffu - p));
                     }
                 }
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
 #pragma unroll
         for (int m = 0; m < APT; ++m) {
             if (!valid[m]) continue;
-            const size_t o = o0 + m * ASSIGN_BLOCK;
+            const size_t o = o0 + m * MSTRIDE;
             const bool in_lds = bidx[m] >= c_last;
             const float4 g = in_lds ? s_raw[bidx[m] - c_last] : gt_boxes[g0 + bidx[m]];
             const int64_t lbl = in_lds ? s_lbl[bidx[m] - c_last] : gt_labels[g0 + bidx[m]];
