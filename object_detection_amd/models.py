@@ -46,7 +46,8 @@ class _BoxOps:
         self._dev_tables = {}
 
     def _table(self, t: torch.Tensor, device) -> torch.Tensor:
-        key = (id(t), str(device))
+        device = torch.device(device)
+        key = (id(t), device.type, device.index)
         if key not in self._dev_tables:
             self._dev_tables[key] = t.to(device=device, dtype=torch.float32).contiguous()
         return self._dev_tables[key]

@@ -47,9 +47,43 @@ def _stream(device) -> int:
 _POISON = bool(os.environ.get('DETBOX_POISON_WORKSPACE'))
 
 
-def _workspace(device, nbytes: int, tag: str) -> torch.Tensor:
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _on(device):
+    """Device guard for a launch; nothing to do (and nothing spent) when the device is already current."""
+    return _NO_GUARD if torch.cuda.current_device() == device.index else torch.cuda.device(device)
+
+
+def _to(t: torch.Tensor, device) -> torch.Tensor:
+    return t if t.device == device else t.to(device)
+
+
+_ws_sizes = {}
+
+
+def _ws_bytes(fn, *args) -> int:
+    """Workspace size of an operator for one set of sizes, asked from the library once."""
+    key = (fn.__name__, args)
+    n = _ws_sizes.get(key)
+    if n is None:
+        if len(_ws_sizes) > 4096:
+            _ws_sizes.clear()
+        n = _ws_sizes[key] = int(fn(*args))
+    return n
+
+
+def _workspace(device, nbytes: int, tag: str, stream: Optional[int] = None) -> torch.Tensor:
     """Grow-only scratch buffer per (device, operator, stream): calls that share one are ordered on that stream."""
-    key = (device.index, tag, _stream(device))
+    key = (device.index, tag, _stream(device) if stream is None else stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
@@ -64,6 +98,8 @@ def _dense(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[torch.Ten
     tensor of the right type, a copy for a strided view or a slice that starts off a 16-byte boundary."""
     if t is None:
         return None
+    if t.dtype is dtype and t.is_contiguous() and not (t.data_ptr() & 15):
+        return t
     if t.dtype is not dtype:
         t = t.to(dtype)
     if not t.is_contiguous():
@@ -88,7 +124,7 @@ def box_convert(boxes: torch.Tensor, in_fmt: str, out_fmt: str) -> torch.Tensor:
     dev = boxes.device if boxes.is_cuda else _device()
     b = _f32(boxes, dev).reshape(-1, 4)
     out = torch.empty_like(b)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.lib().detbox_box_convert(_ptr(b), _ptr(out), b.shape[0], FMT[in_fmt], FMT[out_fmt], _stream(dev)),
                    'detbox_box_convert')
     return out.reshape(boxes.shape).to(src_device)
@@ -99,7 +135,7 @@ def box_iou(boxes1: torch.Tensor, boxes2: torch.Tensor) -> torch.Tensor:
     dev = boxes1.device if boxes1.is_cuda else _device()
     b1, b2 = _f32(boxes1, dev), _f32(boxes2, dev)
     out = torch.empty((b1.shape[0], b2.shape[0]), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.lib().detbox_box_iou(_ptr(b1), b1.shape[0], _ptr(b2), b2.shape[0], _ptr(out), _stream(dev)),
                    'detbox_box_iou')
     return out.to(src_device)
@@ -113,7 +149,7 @@ def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, i
     if n == 0:
         return torch.empty((0,), dtype=torch.int64, device=src_device)
     dev = boxes.device if boxes.is_cuda else _device()
-    with torch.cuda.device(dev):
+    with _on(dev):
         b, s = _f32(boxes, dev), _f32(scores, dev)
         cls = idxs.to(dev)
         # group by class (stable: original order inside a class); long classes are pre-sorted by score
@@ -172,11 +208,12 @@ def assign_anchor(anchors: torch.Tensor, gt_boxes: torch.Tensor, gt_labels: torc
     matched = torch.empty((B, P), dtype=torch.int64, device=dev)
     best = torch.empty((max(total_gt, 1),), dtype=torch.int64, device=dev) if want_best else None
     L = _lib.lib()
-    with torch.cuda.device(dev):
-        ws = _workspace(dev, L.detbox_assign_anchor_workspace_bytes(total_gt), 'assign')
+    with _on(dev):
+        st = _stream(dev)
+        ws = _workspace(dev, _ws_bytes(L.detbox_assign_anchor_workspace_bytes, total_gt), 'assign', st)
         _lib.check(L.detbox_assign_anchor(mode, _ptr(anchors), P, _ptr(gt_boxes), _ptr(gt_labels), _ptr(gt_offsets),
                                           B, total_gt, thr_lo, thr_hi, _ptr(locs), _ptr(labels), _ptr(matched),
-                                          _ptr(best), ws.data_ptr(), ws.numel(), _stream(dev)), 'detbox_assign_anchor')
+                                          _ptr(best), ws.data_ptr(), ws.numel(), st), 'detbox_assign_anchor')
     if want_best:
         return locs, labels, matched, best[:total_gt]
     return locs, labels, matched
@@ -194,7 +231,7 @@ def assign_fcos(points: torch.Tensor, ranges: torch.Tensor, gt_boxes, gt_labels,
     cents = torch.empty((B, P), dtype=torch.float32, device=dev)
     labels = torch.empty((B, P), dtype=torch.int64, device=dev)
     matched = torch.empty((B, P), dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.lib().detbox_assign_fcos(_ptr(points), _ptr(ranges), P, _ptr(gt_boxes), _ptr(gt_labels),
                                                  _ptr(gt_offsets), B, total_gt, _ptr(locs), _ptr(cents), _ptr(labels),
                                                  _ptr(matched), _stream(dev)), 'detbox_assign_fcos')
@@ -219,7 +256,7 @@ def activate_scores(head: torch.Tensor, extra: Optional[torch.Tensor], activatio
     head, extra = _dense(head), _dense(extra)
     B, P, C = head.shape
     out = torch.empty_like(head)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.lib().detbox_activate_scores(activation, _ptr(head), _ptr(extra), B, P, C, _ptr(out), _stream(dev)),
                    'detbox_activate_scores')
     return out
@@ -234,7 +271,7 @@ def select_decode(scores: torch.Tensor, locs: torch.Tensor, anchors: torch.Tenso
     dev = scores.device
     if not scores.is_cuda:
         raise _lib.DetboxError('select_decode runs on a ROCm device only')
-    scores, locs, anchors, extra = _dense(scores), _dense(locs.to(dev)), _dense(anchors.to(dev)), _dense(None if extra is None else extra.to(dev))
+    scores, locs, anchors, extra = _dense(scores), _dense(_to(locs, dev)), _dense(_to(anchors, dev)), _dense(None if extra is None else _to(extra, dev))
     B, P, C = scores.shape
     if locs.shape != (B, P, 4) or anchors.shape[0] != P or (extra is not None and extra.shape != (B, P)):
         raise ValueError(f'select_decode: shapes {tuple(scores.shape)}, {tuple(locs.shape)}, {tuple(anchors.shape)} do not fit')
@@ -246,12 +283,13 @@ def select_decode(scores: torch.Tensor, locs: torch.Tensor, anchors: torch.Tenso
     seg = torch.empty((B, S + 1), dtype=torch.int32, device=dev)
     counts = torch.empty((B,), dtype=torch.int32, device=dev)
     L = _lib.lib()
-    with torch.cuda.device(dev):
-        ws = _workspace(dev, L.detbox_select_decode_workspace_bytes(B, P, C, class_begin, top_k, activation), 'select')
+    with _on(dev):
+        st = _stream(dev)
+        ws = _workspace(dev, _ws_bytes(L.detbox_select_decode_workspace_bytes, B, P, C, class_begin, top_k, activation), 'select', st)
         _lib.check(L.detbox_select_decode(decode_mode, activation, _ptr(scores), _ptr(extra), _ptr(locs), _ptr(anchors),
                                           B, P, C, class_begin, class_id_offset, conf_thresh, top_k, score_hi_hint,
                                           out_boxes.data_ptr(), out_scores.data_ptr(), out_cls.data_ptr(),
-                                          seg.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
+                                          seg.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(), st),
                    'detbox_select_decode')
     return Candidates(out_boxes, out_scores, out_cls, seg, counts, top_k)
 
@@ -268,11 +306,12 @@ def nms_segments(boxes: torch.Tensor, scores: torch.Tensor, seg_offsets: torch.T
     keep = torch.empty((B, stride), dtype=torch.int64, device=dev)
     kc = torch.empty((B,), dtype=torch.int32, device=dev)
     L = _lib.lib()
-    with torch.cuda.device(dev):
-        ws = _workspace(dev, L.detbox_batched_nms_segments_workspace_bytes(B, stride, S), 'nms')
+    with _on(dev):
+        st = _stream(dev)
+        ws = _workspace(dev, _ws_bytes(L.detbox_batched_nms_segments_workspace_bytes, B, stride, S), 'nms', st)
         _lib.check(L.detbox_batched_nms_segments(_ptr(boxes), _ptr(scores), _ptr(seg_offsets), B, stride, S,
                                                  int(max_segment), float(iou_threshold), int(presorted),
-                                                 _ptr(keep), kc.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
+                                                 _ptr(keep), kc.data_ptr(), ws.data_ptr(), ws.numel(), st),
                    'detbox_batched_nms_segments')
     return keep, kc
 
@@ -288,15 +327,15 @@ def pack_detections(boxes, scores, class_ids, keep, keep_counts, image_ids: torc
     returned as a fourth value."""
     dev = boxes.device
     boxes, scores, class_ids, keep = _dense(boxes), _dense(scores), _dense(class_ids, torch.int64), _dense(keep, torch.int64)
-    keep_counts, image_sizes = _dense(keep_counts, torch.int32), _dense(image_sizes.to(dev), torch.int32)
-    image_ids = _dense(image_ids.to(dev), torch.int64)
+    keep_counts, image_sizes = _dense(keep_counts, torch.int32), _dense(_to(image_sizes, dev), torch.int32)
+    image_ids = _dense(_to(image_ids, dev), torch.int64)
     B, stride = scores.shape
     if boxes.shape != (B, stride, 4) or keep.shape != (B, stride) or image_ids.numel() != B or image_sizes.shape != (B, 2):
         raise ValueError('pack_detections: shapes do not fit')
     rows_ids = torch.empty((B * stride, 2), dtype=torch.int64, device=dev)
     rows_vals = torch.empty((B * stride, 5), dtype=torch.float64, device=dev)
     row_off = torch.empty((B + 1,), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         if wire_images_cap is None:
             _lib.check(_lib.lib().detbox_pack_detections(_ptr(boxes), _ptr(scores), _ptr(class_ids), _ptr(keep),
                                                          keep_counts.data_ptr(), image_ids.data_ptr(), image_sizes.data_ptr(),
@@ -325,7 +364,7 @@ class _FocalLossSum(torch.autograd.Function):
         x = _dense(logits.detach().reshape(-1, C))
         t = labels.reshape(-1).to(device=dev, dtype=torch.int64).contiguous()
         out = torch.empty((), dtype=torch.float64, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(_lib.lib().detbox_focal_loss_forward(_ptr(x), _ptr(t), x.shape[0], C, float(alpha), float(gamma),
                                                             out.data_ptr(), _stream(dev)), 'detbox_focal_loss_forward')
         ctx.save_for_backward(x, t)
@@ -338,7 +377,7 @@ class _FocalLossSum(torch.autograd.Function):
         dev = x.device
         gs = grad_out.detach().to(device=dev, dtype=torch.float32).reshape(1).contiguous()
         grad = torch.empty_like(x)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(_lib.lib().detbox_focal_loss_backward(_ptr(x), _ptr(t), x.shape[0], x.shape[1], ctx.alpha, ctx.gamma,
                                                              gs.data_ptr(), _ptr(grad), _stream(dev)),
                        'detbox_focal_loss_backward')
@@ -367,7 +406,7 @@ class _SmoothL1MaskedSum(torch.autograd.Function):
         if y.shape != x.shape or t.numel() != x.shape[0]:
             raise ValueError('smooth_l1_masked_sum: input, target [..., 4] and labels [...] do not fit')
         out = torch.empty((), dtype=torch.float64, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(_lib.lib().detbox_smooth_l1_masked_forward(_ptr(x), _ptr(y), _ptr(t), x.shape[0], out.data_ptr(),
                                                                   _stream(dev)), 'detbox_smooth_l1_masked_forward')
         ctx.save_for_backward(x, y, t)
@@ -380,7 +419,7 @@ class _SmoothL1MaskedSum(torch.autograd.Function):
         dev = x.device
         gs = grad_out.detach().to(device=dev, dtype=torch.float32).reshape(1).contiguous()
         grad = torch.empty_like(x)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(_lib.lib().detbox_smooth_l1_masked_backward(_ptr(x), _ptr(y), _ptr(t), x.shape[0], gs.data_ptr(),
                                                                    _ptr(grad), _stream(dev)), 'detbox_smooth_l1_masked_backward')
         return grad.reshape(ctx.shape).to(ctx.dtype), None, None
@@ -413,7 +452,7 @@ def pack_wire(boxes, scores, class_ids, keep, keep_counts, image_ids: torch.Tens
     if B > images_cap:
         raise ValueError('pack_wire: more images than images_cap')
     wire = torch.empty((wire_header_rows(images_cap) + B * stride, 6), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.lib().detbox_pack_wire(_ptr(boxes), _ptr(scores), _ptr(class_ids), _ptr(keep),
                                                keep_counts.data_ptr(), image_ids.data_ptr(), image_sizes.data_ptr(),
                                                B, stride, int(images_cap), wire.data_ptr(), _stream(dev)),
@@ -436,7 +475,7 @@ def topk_mask(values: torch.Tensor, k: torch.Tensor) -> torch.Tensor:
     if kk.numel() != B:
         raise ValueError('k must hold one count per row')
     out = torch.empty((B, P), dtype=torch.bool, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.lib().detbox_topk_mask(_ptr(v), _ptr(kk), B, P, _ptr(out), _stream(dev)), 'detbox_topk_mask')
     return out if values.is_cuda else out.to(values.device)
 
