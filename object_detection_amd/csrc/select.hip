@@ -1440,7 +1440,8 @@ SelPlan make_plan(int64_t B, int64_t P, int64_t C, int64_t Cs, int top_k) {
         sp.ns_cap = SUB_ROWS; sp.blk_cap = 256;
         return sp;
     }
-    int rate = P >= 65536 ? 16 : (P >= 16384 ? 8 : 4);
+    static const int rate_big = [] { const char *e = std::getenv("DETBOX_SAMPLE_RATE"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 32; }();
+    int rate = P >= 65536 ? rate_big : (P >= 16384 ? 8 : 4);
     double upper = 0.0;
     for (;;) {
         const double kr = (double)top_k / rate;
