@@ -213,11 +213,15 @@ __device__ inline bool subtile_scores(const float *s_tile, const float *__restri
 // Runs f(x, valid, first_anchor_of_subtile, ctx) over sub-tiles first, first+step, ... (< last) of image b
 // with the double-buffered DMA pipeline; after(s) runs once per sub-tile behind the barrier
 // (block-uniform work such as a flush).  s_tiles holds two buffers of tile_floats floats.
-template <int ACT, int EPT, typename F, typename G>
+struct NoStart { __device__ void operator()() const {} };
+
+// `start` runs once, after the DMA of the first sub-tile has been issued and before anybody waits for it: the place
+// for a kernel's own set-up loads, which would otherwise leave the memory pipe idle at the head of every workgroup.
+template <int ACT, int EPT, typename F, typename G, typename H = NoStart>
 __device__ inline void for_each_subtile(const float *__restrict__ in, const float *__restrict__ extra, int b, int P,
                                         int C, long long total_floats, long long first, long long last,
-                                        long long step, float *s_tiles, int tile_floats, F f, G after) {
-    if (first >= last) return;
+                                        long long step, float *s_tiles, int tile_floats, F f, G after, H start = H()) {
+    if (first >= last) { start(); return; }
     auto geom = [&](long long s) {
         const int r0 = (int)s * SUB_ROWS;
         return sub_geom(in, (long long)b * P + r0, min(SUB_ROWS, P - r0), C);
@@ -225,6 +229,7 @@ __device__ inline void for_each_subtile(const float *__restrict__ in, const floa
     SubGeom g = geom(first);
     int buf = 0;
     dma_issue<EPT>(g, s_tiles);
+    start();
     __syncthreads();
     for (long long s = first; s < last; s += step) {
         const bool more = s + step < last;
@@ -579,14 +584,17 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
         wn += ln;
         ln = 0u;
     };
-    // the lane's classes never change: their staging thresholds live in registers
+    // the lane's classes never change: their staging thresholds live in registers (loaded while the first sub-tile's
+    // DMA is in flight)
     const int r = tid / LPR, sub = tid % LPR;
     float tlo[EPT];
+    auto load_thresholds = [&]() {
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-        const int c = sub + LPR * i;
-        tlo[i] = (c >= cb && c < C && rb[c - cb].mode == RULE_STAGED) ? rb[c - cb].min_score : __builtin_inff();
-    }
+        for (int i = 0; i < EPT; ++i) {
+            const int c = sub + LPR * i;
+            tlo[i] = (c >= cb && c < C && rb[c - cb].mode == RULE_STAGED) ? rb[c - cb].min_score : __builtin_inff();
+        }
+    };
 
     // Workgroup j of an image takes sub-tiles j, j + gx, j + 2 gx, ...: at any moment the workgroups of an image read
     // one compact window of it (3 % faster than a contiguous run per workgroup).
@@ -655,7 +663,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
             }
         },
         // behind the barrier: the stores have the whole next sub-tile to complete before a barrier waits for them
-        [&](long long) { if (ln >= (uint32_t)SCAN_EBUF / 2u) flush(); });
+        [&](long long) { if (ln >= (uint32_t)SCAN_EBUF / 2u) flush(); }, load_thresholds);
     flush();
     if ((tid & 63) == 0) {
         blk_cnt[blk * 4 + wv] = wn < wcap ? wn : wcap;
