@@ -1227,8 +1227,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void direct_stats_kernel(const float *_
     if (tid < sp.Cs && s_cnt[tid]) atomicAdd(&npos[(size_t)b * sp.Cs + tid], s_cnt[tid]);
 }
 
-template <int DECODE>
-__global__ __launch_bounds__(256) void direct_select_kernel(
+template <int DECODE, int BLK>
+__global__ __launch_bounds__(BLK) void direct_select_kernel(
     const float *__restrict__ colscores, SelParams sp, const uint32_t *__restrict__ npos,
     const float4 *__restrict__ locs, const float *__restrict__ anchors, int class_id_offset,
     float4 *__restrict__ out_boxes, float *__restrict__ out_scores, int64_t *__restrict__ out_cls,
@@ -1236,8 +1236,9 @@ __global__ __launch_bounds__(256) void direct_select_kernel(
     extern __shared__ uint32_t s_d[];                  // [P] ordered score keys above the threshold, 0 = not a candidate
     __shared__ __align__(16) uint32_t s_h[256];
     __shared__ uint32_t s_h16[16 * 257];
-    __shared__ uint32_t s_pref, s_need, s_row0;
-    __shared__ uint32_t s_wgt[4], s_weq[4];
+    __shared__ uint32_t s_lo, s_hi, s_state, s_need, s_row0;
+    constexpr int W = BLK / 64;
+    __shared__ uint32_t s_wgt[W], s_weq[W];
     const int ci = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1252,7 +1253,7 @@ __global__ __launch_bounds__(256) void direct_select_kernel(
         uint32_t acc = 0u;
         for (int t = 0; t < ci; ++t) acc += s_n[t];
         s_row0 = acc;
-        s_pref = 0u;
+        s_lo = 0xffffffffu; s_hi = 0u; s_state = 0u; s_need = k;
         if (ci == 0) {
             int32_t *so = seg_off + (size_t)b * (Cs + 1);
             for (int t = 0; t < Cs; ++t) { so[t] = (int32_t)acc; acc += s_n[t]; }
@@ -1267,37 +1268,57 @@ __global__ __launch_bounds__(256) void direct_select_kernel(
     // the class's scores as keys (eight loads in flight per thread: the column is read once and the read is all latency)
     const int c = ci + sp.cb;
     const float *col = colscores + ((size_t)b * Cs + ci) * P;
-    for (int base = tid; base < P; base += 256 * 8) {
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
+    for (int base = tid; base < P; base += BLK * 8) {
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int p = base + u * 256;
+            const int p = base + u * BLK;
             v[u] = p < P ? col[p] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int p = base + u * 256;
-            if (p < P) s_d[p] = v[u] > sp.thr ? okey(v[u]) - sp.key_thr : 0u;
+            const int p = base + u * BLK;
+            if (p < P) {
+                const uint32_t d = v[u] > sp.thr ? okey(v[u]) - sp.key_thr : 0u;
+                s_d[p] = d;
+                if (d) { kmin = min(kmin, d); kmax = max(kmax, d); }
+            }
         }
     }
+    if (kmax) { atomicMin(&s_lo, kmin); atomicMax(&s_hi, kmax); }
     __syncthreads();
-    // the top_k-th largest key d* and how many keys equal to it are taken (lowest anchors first)
+    // the top_k-th largest key d* and how many keys equal to it are taken (lowest anchors first): a radix search that
+    // narrows the interval [lo, hi] of candidate keys, 256 bins over what is left of it per round (the scores of a class
+    // crowd into a few exponents: bins over the whole key range would put nearly all of them into two or three).  It
+    // ends when a bin is a single key value, or holds a single key -- typically after two rounds.
     uint32_t dstar = 0u, need_eq = 0u;
     if (n_pos > k) {
-        if (tid == 0) s_need = k;
-        for (int shift = 24; shift >= 0; shift -= 8) {
-            // scores of one class crowd into a few digits: sixteen copies of the histogram (one per lane modulo 16,
-            // 257 words apart so that equal digits fall into different banks) keep the LDS atomics from serialising
-            for (int i = tid; i < 16 * 257; i += 256) s_h16[i] = 0u;
+        for (int round = 0; round < 6; ++round) {
+            // sixteen copies of the histogram (one per lane modulo 16, 257 words apart so that equal digits fall into
+            // different banks) keep the LDS atomics from serialising
+            for (int i = tid; i < 16 * 257; i += BLK) s_h16[i] = 0u;
             __syncthreads();
-            const uint32_t pref = s_pref;
+            const uint32_t lo = s_lo, hi = s_hi;
+            const uint32_t span = hi - lo;
+            const int sb = span ? 32 - __clz((int)span) : 0;
+            const int sh = sb > 8 ? sb - 8 : 0;
             uint32_t *mine = s_h16 + (lane & 15) * 257;
-            for (int p = tid; p < P; p += 256) {
-                const uint32_t d = s_d[p];
-                if (d && (shift == 24 || (d >> (shift + 8)) == (pref >> (shift + 8)))) atomicAdd(&mine[(d >> shift) & 255u], 1u);
+            for (int base = tid; base < P; base += BLK * 8) {          // eight keys per trip: the reads overlap
+                uint32_t d8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int p = base + u * BLK;
+                    d8[u] = p < P ? s_d[p] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t d = d8[u];
+                    if (d >= lo && d <= hi) atomicAdd(&mine[(d - lo) >> sh], 1u);       // lo >= 1: a zero is never counted
+                }
             }
             __syncthreads();
-            {
+            if (tid < 256) {
                 uint32_t acc = 0u;
 #pragma unroll
                 for (int cpy = 0; cpy < 16; ++cpy) acc += s_h16[cpy * 257 + tid];
@@ -1310,22 +1331,44 @@ __global__ __launch_bounds__(256) void direct_select_kernel(
                 const uint32_t suf = suffix_scan64(t, lane);
                 uint32_t digit, above, nd;
                 find_kth_bin(q, suf, t, lane, s_need, digit, above, nd);
-                if (lane == 0) { s_pref = pref | (digit << shift); s_need -= above; }
+                if (lane == 0) {
+                    const uint32_t nlo = lo + (digit << sh);
+                    uint32_t nhi = nlo + ((1u << sh) - 1u);
+                    if (nhi > hi || nhi < nlo) nhi = hi;
+                    s_lo = nlo; s_hi = nhi; s_need -= above;
+                    s_state = sh == 0 ? 1u : (nd == 1u ? 2u : 0u);   // 1: the bin is one key value; 2: it holds one key
+                }
+            }
+            __syncthreads();
+            if (s_state) break;
+        }
+        if (s_state == 2u) {                               // the one key inside [lo, hi]
+            const uint32_t lo = s_lo, hi = s_hi;
+            for (int p = tid; p < P; p += BLK) {
+                const uint32_t d = s_d[p];
+                if (d >= lo && d <= hi) s_lo = d;
             }
             __syncthreads();
         }
-        dstar = s_pref;
+        dstar = s_lo;
         need_eq = s_need;                                 // >= 1: the key d* itself is among the top_k
     }
     // wave w walks anchors [w*Q, (w+1)*Q): first the totals per wave, then ranks and output
-    const int Q = ((P + 255) / 256) * 64;
+    const int Q = ((P + BLK - 1) / BLK) * 64;
     const int p_lo = wv * Q, p_hi = min(P, p_lo + Q);
     uint32_t gt = 0u, eq = 0u;
-    for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
-        const int p = p0 + lane;
-        const uint32_t d = p < p_hi ? s_d[p] : 0u;
-        gt += (uint32_t)__popcll(__ballot(d > dstar));
-        eq += (uint32_t)__popcll(__ballot(d == dstar && d != 0u));
+    for (int p0 = p_lo; p0 < p_hi; p0 += 64 * 4) {
+        uint32_t d4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * 64 + lane;
+            d4[u] = p < p_hi ? s_d[p] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            gt += (uint32_t)__popcll(__ballot(d4[u] > dstar));
+            eq += (uint32_t)__popcll(__ballot(d4[u] == dstar && d4[u] != 0u));
+        }
     }
     if (lane == 0) { s_wgt[wv] = gt; s_weq[wv] = eq; }
     __syncthreads();
@@ -1339,24 +1382,33 @@ __global__ __launch_bounds__(256) void direct_select_kernel(
     // winners into LDS at their rank first; the decode and the output rows then go out in one dense pass (the gathers
     // of a sparse, lane-masked loop would each wait out their own latency)
     unsigned long long *s_win = reinterpret_cast<unsigned long long *>(s_d + ((P + 1) & ~1));
-    for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
-        const int p = p0 + lane;
-        const uint32_t d = p < p_hi ? s_d[p] : 0u;
-        const bool is_eq = d == dstar && d != 0u;
-        const unsigned long long em = __ballot(is_eq);
-        const uint32_t my_eq = eq_before + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
-        const bool sel = d > dstar || (is_eq && my_eq < need_eq);
-        const unsigned long long sm = __ballot(sel);
-        if (sel) {
-            const uint32_t rank = sel_before + __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
-            if (rank < n_sel) s_win[rank] = ((unsigned long long)d << 32) | (uint32_t)p;
+    for (int q0 = p_lo; q0 < p_hi; q0 += 64 * 4) {
+        uint32_t d4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = q0 + u * 64 + lane;
+            d4[u] = p < p_hi ? s_d[p] : 0u;
         }
-        eq_before += (uint32_t)__popcll(em);
-        sel_before += (uint32_t)__popcll(sm);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = q0 + u * 64 + lane;
+            const uint32_t d = d4[u];
+            const bool is_eq = d == dstar && d != 0u;
+            const unsigned long long em = __ballot(is_eq);
+            const uint32_t my_eq = eq_before + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+            const bool sel = d > dstar || (is_eq && my_eq < need_eq);
+            const unsigned long long sm = __ballot(sel);
+            if (sel) {
+                const uint32_t rank = sel_before + __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
+                if (rank < n_sel) s_win[rank] = ((unsigned long long)d << 32) | (uint32_t)p;
+            }
+            eq_before += (uint32_t)__popcll(em);
+            sel_before += (uint32_t)__popcll(sm);
+        }
     }
     __syncthreads();
     const size_t row0 = (size_t)b * ((size_t)Cs * sp.top_k) + s_row0;
-    for (uint32_t rank = (uint32_t)tid; rank < n_sel; rank += 256u) {
+    for (uint32_t rank = (uint32_t)tid; rank < n_sel; rank += (uint32_t)BLK) {
         const unsigned long long w = s_win[rank];
         const uint32_t p = (uint32_t)w, d = (uint32_t)(w >> 32);
         const float4 l = locs[(size_t)b * P + p];
@@ -1775,15 +1827,19 @@ extern "C" int detbox_select_decode(int decode_mode, int activation, const float
         const float4 *l4 = reinterpret_cast<const float4 *>(locs);
         float4 *ob = reinterpret_cast<float4 *>(out_boxes);
         ProfScope ps("select_direct", s);
-#define DETBOX_DIRECT(D)                                                                                          \
+        // few lists (fewer than two per CU): four times the threads per list, the kernel is one workgroup's latency
+        const bool wide = Cs * B <= 512;
+#define DETBOX_DIRECT_BLK(D, BLKC)                                                                                \
     {                                                                                                             \
-        if (int rc2 = set_lds(direct_select_kernel<D>, lds)) return rc2;                                          \
-        direct_select_kernel<D><<<dim3((unsigned)Cs, (unsigned)B), dim3(256), lds, s>>>(                          \
+        if (int rc2 = set_lds(direct_select_kernel<D, BLKC>, lds)) return rc2;                                    \
+        direct_select_kernel<D, BLKC><<<dim3((unsigned)Cs, (unsigned)B), dim3(BLKC), lds, s>>>(                   \
             colscores, sp, npos, l4, anchors, class_id_offset, ob, out_scores, out_class_ids, out_seg_offsets, out_counts); \
     }
+#define DETBOX_DIRECT(D) { if (wide) DETBOX_DIRECT_BLK(D, 1024) else DETBOX_DIRECT_BLK(D, 256) }
         if (decode_mode == DETBOX_DECODE_CXCYWH) DETBOX_DIRECT(DETBOX_DECODE_CXCYWH)
         else if (decode_mode == DETBOX_DECODE_YOLO) DETBOX_DIRECT(DETBOX_DECODE_YOLO)
         else DETBOX_DIRECT(DETBOX_DECODE_FCOS)
+#undef DETBOX_DIRECT_BLK
 #undef DETBOX_DIRECT
         DETBOX_LAUNCH_CHECK();
         return DETBOX_OK;
