@@ -1248,8 +1248,9 @@ __global__ __launch_bounds__(ML_THREADS) void nms_merge_lds_kernel(
     if (tid < F) s_src[tid] = so[min(S, s0 + tid)] - (ko[min(s1, s0 + tid)] - out0);
     __syncthreads();
     for (int e = tid; e < total; e += ML_THREADS) {      // independent loads: the runs sit at their segment starts
-        int r = 0;
-        while (s_off[r + 1] <= e) ++r;
+        int r = 0;                                        // the run that holds element e: largest r with s_off[r] <= e
+        for (int step = 32; step > 0; step >>= 1)
+            if (r + step < F && s_off[r + step] <= e) r += step;
         cur[e] = src[base + s_src[r] + e];
     }
     __syncthreads();
@@ -1258,8 +1259,9 @@ __global__ __launch_bounds__(ML_THREADS) void nms_merge_lds_kernel(
         int o = min(tid * per, total);
         const int o_end = min(o + per, total);
         while (o < o_end) {
-            int pr = 0;                        // pair containing output position o
-            while (s_off[min(F, (pr + 1) * 2 * g)] <= o) ++pr;
+            int pr = 0;                        // pair containing output position o: largest pr with s_off[pr*2g] <= o
+            for (int step = 32; step > 0; step >>= 1)
+                if ((pr + step) * 2 * g < F && s_off[(pr + step) * 2 * g] <= o) pr += step;
             const int a_lo = s_off[min(F, pr * 2 * g)], a_hi = s_off[min(F, pr * 2 * g + g)];
             const int b_hi = s_off[min(F, (pr + 1) * 2 * g)];
             const int na = a_hi - a_lo, nb = b_hi - a_hi;
