@@ -1,4 +1,4 @@
-"""The maintainer-side binding shown in INTEGRATION.md: the snippet there is executed as written, on a stand-in for
+"""The maintainer-side binding snippet of the integration guide is executed as written, on a stand-in for
 the reference's model object, and (on a GPU) driven in the order of src/train.py:148-156 / src/test.py:95-99."""
 import inspect
 import os

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything `profiles/` holds for one round, from the default bench command.  Run on the GPU box from the repo root:
+# Everything `profiles/` holds under one tag, from the default bench command.  Run on the GPU box from the repo root:
 #   bash tools/profile_round.sh <tag>
 # kernel trace + stats (default command, and one batch at a time), HBM traffic (FETCH_SIZE and WRITE_SIZE, a pass each),
 # SQ instruction counters (one pass), and the kernel trace of the SSD300 workload.
