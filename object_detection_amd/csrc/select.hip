@@ -217,11 +217,12 @@ struct NoStart { __device__ void operator()() const {} };
 
 // `start` runs once, after the DMA of the first sub-tile has been issued and before anybody waits for it: the place
 // for a kernel's own set-up loads, which would otherwise leave the memory pipe idle at the head of every workgroup.
-template <int ACT, int EPT, typename F, typename G, typename H = NoStart>
+template <int ACT, int EPT, typename F, typename G, typename H = NoStart, typename H2 = NoStart>
 __device__ inline void for_each_subtile(const float *__restrict__ in, const float *__restrict__ extra, int b, int P,
                                         int C, long long total_floats, long long first, long long last,
-                                        long long step, float *s_tiles, int tile_floats, F f, G after, H start = H()) {
-    if (first >= last) { start(); return; }
+                                        long long step, float *s_tiles, int tile_floats, F f, G after, H start = H(),
+                                        H2 started = H2()) {
+    if (first >= last) { start(); __syncthreads(); started(); return; }
     auto geom = [&](long long s) {
         const int r0 = (int)s * SUB_ROWS;
         return sub_geom(in, (long long)b * P + r0, min(SUB_ROWS, P - r0), C);
@@ -231,6 +232,7 @@ __device__ inline void for_each_subtile(const float *__restrict__ in, const floa
     dma_issue<EPT>(g, s_tiles);
     start();
     __syncthreads();
+    started();                   // what start() left in LDS is visible
     for (long long s = first; s < last; s += step) {
         const bool more = s + step < last;
         SubGeom gn = g;
@@ -584,15 +586,19 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
         wn += ln;
         ln = 0u;
     };
-    // the lane's classes never change: their staging thresholds live in registers (loaded while the first sub-tile's
-    // DMA is in flight)
+    // the lane's classes never change: their staging thresholds live in registers (fetched into LDS by the first Cs
+    // threads while the first sub-tile's DMA is in flight, then picked up by every lane)
     const int r = tid / LPR, sub = tid % LPR;
     float tlo[EPT];
+    __shared__ float s_tlo[MAX_SEL_CLASSES];
+    auto fetch_thresholds = [&]() {              // one round of loads for the whole workgroup
+        if (tid < Cs) s_tlo[tid] = rb[tid].mode == RULE_STAGED ? rb[tid].min_score : __builtin_inff();
+    };
     auto load_thresholds = [&]() {
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
             const int c = sub + LPR * i;
-            tlo[i] = (c >= cb && c < C && rb[c - cb].mode == RULE_STAGED) ? rb[c - cb].min_score : __builtin_inff();
+            tlo[i] = (c >= cb && c < C) ? s_tlo[c - cb] : __builtin_inff();
         }
     };
 
@@ -663,7 +669,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
             }
         },
         // behind the barrier: the stores have the whole next sub-tile to complete before a barrier waits for them
-        [&](long long) { if (ln >= (uint32_t)SCAN_EBUF / 2u) flush(); }, load_thresholds);
+        [&](long long) { if (ln >= (uint32_t)SCAN_EBUF / 2u) flush(); }, fetch_thresholds, load_thresholds);
     flush();
     if ((tid & 63) == 0) {
         blk_cnt[blk * 4 + wv] = wn < wcap ? wn : wcap;
