@@ -135,6 +135,10 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 
 // Every piece is a 16-byte aligned 16-byte unit that overlaps the tensor, so it lies in a page the tensor owns even when
 // its last bytes are past the tensor's end (those land in slack floats nobody reads).
+// Cache policy of the sub-tile DMA: non-temporal.  Every sub-tile is read exactly once; without the hint the stream
+// is allocated in the L2 and the memory-side cache like reusable data (the scan alone: 155 -> 136 us on
+// 16 x 120087 x 81 logits, 125 -> 105 us when next to nothing is emitted).
+constexpr int DMA_CPOL = 2;      // 'nt' on gfx950
 template <int EPT>
 __device__ inline void dma_issue(const SubGeom &g, float *s_buf) {
     const int tid = threadIdx.x, wbase = tid & ~63;
@@ -142,7 +146,7 @@ __device__ inline void dma_issue(const SubGeom &g, float *s_buf) {
     for (int j = 0; j < EPT / 4 + 1; ++j) {
         const int v = tid + j * SCAN_BLOCK;
         if (v < g.nvec)                                                 // LDS destination = wave-uniform base + lane * 16
-            __builtin_amdgcn_global_load_lds((gptr_t)(g.src + 4 * v), (lptr_t)(s_buf + 4 * (wbase + j * SCAN_BLOCK)), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(g.src + 4 * v), (lptr_t)(s_buf + 4 * (wbase + j * SCAN_BLOCK)), 16, 0, DMA_CPOL);
     }
 }
 
