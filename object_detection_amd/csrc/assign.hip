@@ -205,9 +205,9 @@ __global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
             }
             d.z = 5.0f * logf(g.z / a2[m]);
             d.w = 5.0f * logf(g.w / a3[m]);
-            locs[o] = d;
-            matched[o] = bidx[m];
-            labels[o] = (best[m] < thr_lo) ? 0 : ((best[m] < thr_hi) ? -1 : lbl);
+            store_nt(&locs[o], d);
+            store_nt(&matched[o], (int64_t)bidx[m]);                // the relabelling kernel reads back one row per GT box
+            store_nt(&labels[o], (best[m] < thr_lo) ? (int64_t)0 : ((best[m] < thr_hi) ? (int64_t)-1 : lbl));
         }
     }
 }

@@ -75,4 +75,16 @@ __device__ inline TileOfImage xcd_affine_tile() {
     return t;
 }
 
+// Stores of outputs that nobody on the GPU reads back soon (result rows, training targets, gradients): non-temporal,
+// so that a stream of write-once data does not displace reusable lines from the L2 and the memory-side cache.
+typedef float detbox_v4f __attribute__((ext_vector_type(4)));
+__device__ inline void store_nt(float4 *p, const float4 v) {
+    detbox_v4f x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<detbox_v4f *>(p));
+}
+__device__ inline void store_nt(float *p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ inline void store_nt(double *p, double v) { __builtin_nontemporal_store(v, p); }
+__device__ inline void store_nt(int64_t *p, int64_t v) { __builtin_nontemporal_store(v, p); }
+__device__ inline void store_nt(uint32_t *p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+
 }  // namespace detbox

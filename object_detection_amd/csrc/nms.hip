@@ -1359,11 +1359,11 @@ __global__ __launch_bounds__(256) void pack_detections_kernel(
     }
     __syncthreads();
     const size_t r0 = (size_t)row0 + t0;
-    for (int i = threadIdx.x; i < 5 * nb; i += 256) rows_vals[5 * r0 + i] = s_vals[i];
-    for (int i = threadIdx.x; i < 2 * nb; i += 256) rows_ids[2 * r0 + i] = s_ids[i];
+    for (int i = threadIdx.x; i < 5 * nb; i += 256) store_nt(&rows_vals[5 * r0 + i], s_vals[i]);
+    for (int i = threadIdx.x; i < 2 * nb; i += 256) store_nt(&rows_ids[2 * r0 + i], s_ids[i]);
     if (WIRE) {
         uint32_t *out = wire + 6 * ((size_t)hdr_rows + r0);
-        for (int i = threadIdx.x; i < 6 * nb; i += 256) out[i] = s_wire[i];
+        for (int i = threadIdx.x; i < 6 * nb; i += 256) store_nt(&out[i], s_wire[i]);
     }
 }
 

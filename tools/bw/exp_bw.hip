@@ -95,17 +95,18 @@ __device__ inline SubGeom sub_geom(const float *in, long long row_base, int rows
     g.nvec = (g.nfl + 3) >> 2;
     return g;
 }
-template <int PER>
+template <int PER, int CPOL = 0>
 __device__ inline void dma_issue(const SubGeom &g, float *s_buf) {
     const int tid = threadIdx.x, wbase = tid & ~63;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int v = tid + j * 256;
         if (v < g.nvec)
-            __builtin_amdgcn_global_load_lds((gptr_t)(g.src + 4 * v), (lptr_t)(s_buf + 4 * (wbase + j * 256)), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(g.src + 4 * v), (lptr_t)(s_buf + 4 * (wbase + j * 256)), 16, 0, CPOL);
     }
 }
 struct Rule { unsigned mode, n_sel, beta, n_above; unsigned long long cutoff; float min_score; unsigned pad; };
+template <int CPOL = 0>
 __global__ __launch_bounds__(256) void k_scan_geom(const float *__restrict__ in, int P, int C, int n_sub, int tile_floats, int interleave,
                                                      int subs_per_block, float *out, const Rule *__restrict__ rules = nullptr) {
     extern __shared__ float s_f[];
@@ -131,10 +132,10 @@ __global__ __launch_bounds__(256) void k_scan_geom(const float *__restrict__ in,
     if (first >= last) return;
     SubGeom g = geom(first);
     int buf = 0;
-    dma_issue<7>(g, s_f);
+    dma_issue<7, CPOL>(g, s_f);
     __syncthreads();
     for (long long s = first; s < last; s += step) {
-        if (s + step < last) { const SubGeom gn = geom(s + step); dma_issue<7>(gn, s_f + (buf ^ 1) * tile_floats); }
+        if (s + step < last) { const SubGeom gn = geom(s + step); dma_issue<7, CPOL>(gn, s_f + (buf ^ 1) * tile_floats); }
         acc += s_f[buf * tile_floats + threadIdx.x];
         __syncthreads();
         buf ^= 1;
@@ -200,12 +201,12 @@ int main(int argc, char **argv) {
         const int tile_floats = ((64 * C + 4 * 24 + 8) / 4 + 1) * 4;
         for (int extra : {0, 8192}) {
             const size_t ldsf = 2 * (size_t)tile_floats * 4 + 16 + extra;
-            CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_geom), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
+            CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_geom<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
             for (int gx : {32, 48}) {
                 for (int inter = 0; inter < 2; ++inter) {
                     const int spb = (n_sub + gx - 1) / gx;
                     char nm[96]; snprintf(nm, sizeof nm, "scan geometry gx %d x B 16, interleave %d, LDS %zu", gx, inter, ldsf);
-                    timeit(nm, [&] { k_scan_geom<<<dim3(gx, B), 256, ldsf, 0>>>(buf, P, C, n_sub, tile_floats, inter, spb, out); });
+                    timeit(nm, [&] { k_scan_geom<0><<<dim3(gx, B), 256, ldsf, 0>>>(buf, P, C, n_sub, tile_floats, inter, spb, out); });
                 }
             }
         }
@@ -218,7 +219,16 @@ int main(int argc, char **argv) {
         CK(hipMemset(rules, 0, sizeof(Rule) * B * 80));
         const size_t ldsf = 2 * (size_t)tile_floats * 4 + 16 + 8192;
         const int gx = 32, spb = (n_sub + gx - 1) / gx;
-        timeit("scan geometry gx 32, interleave 1, with the threshold prologue", [&] { k_scan_geom<<<dim3(gx, B), 256, ldsf, 0>>>(buf, P, C, n_sub, tile_floats, 1, spb, out, rules); });
+        timeit("scan geometry gx 32, interleave 1, with the threshold prologue", [&] { k_scan_geom<0><<<dim3(gx, B), 256, ldsf, 0>>>(buf, P, C, n_sub, tile_floats, 1, spb, out, rules); });
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_geom<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_geom<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_geom<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_geom<17>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
+        timeit("scan geometry gx 32, interleave 1, DMA with nt", [&] { k_scan_geom<2><<<dim3(gx, B), 256, ldsf, 0>>>(buf, P, C, n_sub, tile_floats, 1, spb, out); });
+        timeit("scan geometry gx 32, interleave 1, DMA with sc0", [&] { k_scan_geom<1><<<dim3(gx, B), 256, ldsf, 0>>>(buf, P, C, n_sub, tile_floats, 1, spb, out); });
+        timeit("scan geometry gx 32, interleave 1, DMA with sc0 nt", [&] { k_scan_geom<3><<<dim3(gx, B), 256, ldsf, 0>>>(buf, P, C, n_sub, tile_floats, 1, spb, out); });
+        timeit("scan geometry gx 32, interleave 1, DMA with sc0 sc1", [&] { k_scan_geom<17><<<dim3(gx, B), 256, ldsf, 0>>>(buf, P, C, n_sub, tile_floats, 1, spb, out); });
+        timeit("scan geometry gx 48, interleave 1, DMA with nt", [&] { k_scan_geom<2><<<dim3(48, B), 256, ldsf, 0>>>(buf, P, C, n_sub, tile_floats, 1, (n_sub + 47) / 48, out); });
         // a small kernel in front, as in the real chain (the launch gap is not in the kernel's own time, cache state is)
     }
     // the same with random data in the buffer
