@@ -43,8 +43,9 @@ constexpr int PASS_BLOCK = 512;       // fallback streaming passes
 constexpr int MAX_SEL_CLASSES = 128;  // LDS tables are sized for this many selected classes
 constexpr int MAX_TILE_ANCHORS = 16384;
 constexpr int SCAN_BLOCK = 256;
-constexpr int LPR = 4;                // lanes that share one anchor row (8 was measured: no faster)
+constexpr int LPR = 4;                // lanes that share one anchor row (8, with 512 threads, was measured: no faster)
 constexpr int SUB_ROWS = SCAN_BLOCK / LPR;   // anchors per LDS sub-tile
+constexpr int SCAN_WAVES = SCAN_BLOCK / 64;  // every wave of a scan workgroup keeps its own candidate list
 constexpr int SCAN_EBUF = 256;        // entries of a scan wave's staging buffer in LDS
 constexpr int SAMPLE_SUBS = 4;        // sampled sub-tiles per workgroup of select_sample
 constexpr int BITMAP_MAX_WORDS = 4096;  // finalize orders by anchor through a P-bit LDS bitmap up to this
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
     const size_t blk = (size_t)b * gridDim.x + blockIdx.x;
     // every wave appends to its own quarter of the workgroup's list: no atomics, a wave-uniform count
     const int wv = tid >> 6;
-    const uint32_t wcap = (uint32_t)sp.blk_cap >> 2;
+    const uint32_t wcap = (uint32_t)sp.blk_cap / SCAN_WAVES;
     unsigned long long *wlist = blk_list + blk * sp.blk_cap + (size_t)wv * wcap;
     uint32_t wn = 0, ln = 0;                              // entries flushed to the list; entries waiting in the LDS buffer
     unsigned long long *ebuf = reinterpret_cast<unsigned long long *>(s_dynf + 2 * (size_t)sp.tile_floats + 4) + (size_t)wv * SCAN_EBUF;
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
         [&](long long) { if (ln >= (uint32_t)SCAN_EBUF / 2u) flush(); }, fetch_thresholds, load_thresholds);
     flush();
     if ((tid & 63) == 0) {
-        blk_cnt[blk * 4 + wv] = wn < wcap ? wn : wcap;
+        blk_cnt[blk * SCAN_WAVES + wv] = wn < wcap ? wn : wcap;
         if (wn > wcap) img_ovf[b] = 1u;                   // the image falls back to the exact path
     }
 }
@@ -690,17 +691,20 @@ __global__ __launch_bounds__(256) void select_bucket_kernel(SelParams sp, const 
     __shared__ uint32_t s_ccount[MAX_SEL_CLASSES], s_cbase[MAX_SEL_CLASSES];
     const int b = blockIdx.y, tid = threadIdx.x;
     const size_t blk = (size_t)b * gridDim.x + blockIdx.x;
-    const int wcap = sp.blk_cap >> 2;
-    int nw[4];
+    const int wcap = sp.blk_cap / SCAN_WAVES;
+    int nw[SCAN_WAVES];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) nw[w] = (int)blk_cnt[blk * 4 + w];
-    if (nw[0] + nw[1] + nw[2] + nw[3] == 0) return;
+    for (int w = 0; w < SCAN_WAVES; ++w) nw[w] = (int)blk_cnt[blk * SCAN_WAVES + w];
+    int nw_all = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_WAVES; ++w) nw_all += nw[w];
+    if (nw_all == 0) return;
     const unsigned long long *list = blk_list + blk * sp.blk_cap;
     const int Cs = sp.Cs, cap = sp.cap;
     if (tid < MAX_SEL_CLASSES) s_ccount[tid] = 0u;
     __syncthreads();
 #pragma unroll
-    for (int w = 0; w < 4; ++w)
+    for (int w = 0; w < SCAN_WAVES; ++w)
         for (int e = tid; e < nw[w]; e += 256) {
             const uint32_t ci = (uint32_t)(list[w * wcap + e] >> 24) & 0xffu;
             if (ci < (uint32_t)Cs) atomicAdd(&s_ccount[ci], 1u);          // entries are the scan's own; the check costs nothing
@@ -714,7 +718,7 @@ __global__ __launch_bounds__(256) void select_bucket_kernel(SelParams sp, const 
     __syncthreads();
     unsigned long long *stg = staging + (size_t)b * Cs * cap;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < SCAN_WAVES; ++w) {
         for (int e = tid; e < nw[w]; e += 256) {
             const unsigned long long en = list[w * wcap + e];
             const uint32_t ci = (uint32_t)(en >> 24) & 0xffu;
@@ -1554,7 +1558,7 @@ SelLayout layout(int64_t B, int64_t P, int64_t C, int64_t Cs, const SelPlan &pl,
     L.cnt = off; off = align_up(off + (size_t)B * Cs * sizeof(uint32_t), 256);
     L.flag = off; off = align_up(off + sizeof(uint32_t), 256);
     L.img_ovf = off; off = align_up(off + (size_t)B * sizeof(uint32_t), 256);
-    L.blk_cnt = off; off = align_up(off + (size_t)B * pl.scan_gx * 4 * sizeof(uint32_t), 256);
+    L.blk_cnt = off; off = align_up(off + (size_t)B * pl.scan_gx * SCAN_WAVES * sizeof(uint32_t), 256);
     L.rules = off; off = align_up(off + (size_t)B * Cs * sizeof(SelRule), 256);
     L.staging = off; off = align_up(off + (size_t)B * Cs * pl.cap * sizeof(unsigned long long), 256);
     L.samp = off; off = align_up(off + (size_t)B * Cs * pl.ns_cap * sizeof(float), 256);
