@@ -93,6 +93,18 @@ def _workspace(device, nbytes: int, tag: str, stream: Optional[int] = None) -> t
     return ws
 
 
+def release_workspaces(device=None) -> int:
+    """Drops the cached scratch buffers (all of them, or those of one device) and returns how many bytes they held.
+    The buffers are grow-only per (device, operator, stream): after a sweep over very large batches -- the selection
+    reserves 4*B*P*C bytes for its exact fall-back when the activation is fused -- this hands the memory back to the
+    caching allocator.  Only call it when no operator is in flight on the streams concerned."""
+    index = None if device is None else torch.device(device).index
+    freed = 0
+    for key in [k for k in _workspaces if index is None or k[0] == index]:
+        freed += _workspaces.pop(key).numel()
+    return freed
+
+
 def _dense(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[torch.Tensor]:
     """The dtype, dense layout and 16-byte alignment the kernels assume; a no-op for a freshly allocated
     tensor of the right type, a copy for a strided view or a slice that starts off a 16-byte boundary."""

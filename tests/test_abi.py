@@ -80,3 +80,11 @@ def test_model_classes_mirror_reference_interface():
     assert p['iou_thresh'].default == 0.45 and 'classes' in p and 'out_dir' in p
     assert d.SSD300(20).dboxes.shape == (8732, 4) and d.SSD512(20).dboxes.shape == (24564, 4)
     assert d.YoloV3(20).pboxes.shape == (10647, 5) and d.FCOS(20).points.shape == (5456, 2)
+
+
+def test_release_workspaces_empties_the_cache():
+    from object_detection_amd import ops
+    ops._workspaces[(0, 'probe', 0)] = torch.empty(1024, dtype=torch.uint8)
+    ops._workspaces[(1, 'probe', 0)] = torch.empty(512, dtype=torch.uint8)
+    assert ops.release_workspaces('cuda:1') == 512 and (0, 'probe', 0) in ops._workspaces
+    assert ops.release_workspaces() == 1024 and not ops._workspaces
