@@ -7,6 +7,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace detbox {
@@ -30,7 +31,9 @@ struct Sample { hipEvent_t a, b; };
 static std::mutex g_pmu;
 static bool g_prof_on = false;
 static std::map<std::string, std::vector<Sample>> g_samples;
-static std::map<std::string, hipEvent_t> g_open;   // begin event waiting for its end
+// begin events waiting for their end, per (scope, stream): two host threads that launch the same kernel on their own
+// streams do not pair one's begin with the other's end
+static std::map<std::pair<std::string, hipStream_t>, hipEvent_t> g_open;
 static std::vector<hipEvent_t> g_free;             // recycled events
 static std::string g_only;                         // if not empty: the one scope that is timed
 
@@ -46,13 +49,14 @@ void prof_begin(const char *name, hipStream_t s) {
     hipEvent_t ev;
     if (!take_event(&ev)) return;
     (void)hipEventRecord(ev, s);
-    g_open[name] = ev;
+    auto ins = g_open.emplace(std::make_pair(std::string(name), s), ev);
+    if (!ins.second) { g_free.push_back(ins.first->second); ins.first->second = ev; }   // a begin without an end: recycled
 }
 
 void prof_end(const char *name, hipStream_t s) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_pmu);
-    auto it = g_open.find(name);
+    auto it = g_open.find(std::make_pair(std::string(name), s));
     if (it == g_open.end()) return;
     hipEvent_t ev;
     if (!take_event(&ev)) return;

@@ -87,4 +87,18 @@ __device__ inline void store_nt(double *p, double v) { __builtin_nontemporal_sto
 __device__ inline void store_nt(int64_t *p, int64_t v) { __builtin_nontemporal_store(v, p); }
 __device__ inline void store_nt(uint32_t *p, uint32_t v) { __builtin_nontemporal_store(v, p); }
 
+// Inclusive prefix sum over the 64 lanes with data-parallel-primitive moves: shifts inside the rows of 16, then the row
+// totals are broadcast into the following rows.  Every lane of the wave must be active.
+__device__ inline uint32_t wave_inclusive_add(uint32_t v) {
+#define DETBOX_DPP_ADD(ctrl, rows) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, false)
+    DETBOX_DPP_ADD(0x111, 0xf);     // row_shr:1
+    DETBOX_DPP_ADD(0x112, 0xf);     // row_shr:2
+    DETBOX_DPP_ADD(0x114, 0xf);     // row_shr:4
+    DETBOX_DPP_ADD(0x118, 0xf);     // row_shr:8
+    DETBOX_DPP_ADD(0x142, 0xa);     // row_bcast:15 into rows 1 and 3
+    DETBOX_DPP_ADD(0x143, 0xc);     // row_bcast:31 into rows 2 and 3
+#undef DETBOX_DPP_ADD
+    return v;
+}
+
 }  // namespace detbox

@@ -688,21 +688,23 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == 256 
 // in score order:
 //   1. sort (registers, as in the chunked kernel); every wave then owns JPT 64-box chunks of the sorted
 //      order, dealt boustrophedon so that the four waves (one per SIMD) carry equal shares of the triangle;
-//   2. filter: box i (broadcast from LDS) against a wave's 64-box slots with about two VALU instructions per 64
+//   2. filter: box i (broadcast from LDS) against a wave's 64-box slots with three VALU instructions per 64
 //      pairs.  With p = |cx_i - cx_j|, q = |cy_i - cy_j|, W = (w_i + w_j) / 2, H = (h_i + h_j) / 2, the overlaps
 //      satisfy  overlap_x <= W - p,  overlap_y <= H - q,  and  iou > thr  means
 //          overlap_x * overlap_y > t * (A_i + A_j),  t = thr / (1 + thr).
 //      By AM-GM  (W - p) + (H - q) >= 2 sqrt((W - p)(H - q)) > 2 sqrt(t (A_i + A_j)) >= sqrt(2 t) (sqrt A_i + sqrt A_j),
 //      hence     p + q < r_i + r_j,   r = (w + h) / 2 - sqrt(2 t w h)   (>= 0 for thr <= 1).
-//      Centres on a 15-bit grid, radii rounded up: v_sad_u16 gives p + q + (BIAS - r_j) per slot, the minimum
-//      over the wave's slots against BIAS + r_i decides whether anything is near box i at all.  Pairs that pass
-//      (under one per thousand) are appended to the wave's own queue in LDS (no atomics: a wave-uniform count
-//      and mbcnt ranks);
+//      Centres on a 15-bit grid, radii rounded up: v_sad_u16 gives p + q + (BIAS - r_j) per slot, the compare
+//      against BIAS + r_i goes through VCC into a 32-bit history per lane and slot (one bit per box i of a window
+//      of 32).  After each window the set bits (a few pairs per thousand) become entries of the wave's own queue
+//      in LDS: one prefix sum over the lanes' bit counts hands every lane its places, no atomics, no ballots;
 //   3. exact test: the wave drains its queue 64 pairs at a time with the reference's fp32 arithmetic
-//      (division-free where margins decide, the IEEE division in the sliver), compacting the true edges
-//      in place at the front of the queue;
-//   4. resolve: chunk by chunk in score order, edges from earlier chunks remove their targets if the
-//      source was kept, edges inside the chunk form the 64 x 64 words one wave resolves serially.
+//      (division-free where margins decide, the IEEE division in the sliver) on the copy of the sorted boxes
+//      in LDS, compacting the true edges in place at the front of the queue;
+//   4. resolve: a few rounds of  removed' = { j : some edge (i, j) with i not removed }  from the empty set,
+//      one pass over the edges each, until a round changes nothing; long chains of edges take the
+//      chunk-by-chunk form instead (edges from earlier chunks remove their targets if the source was kept,
+//      edges inside the chunk form the 64 x 64 words one wave resolves serially).
 // No barrier inside the all-pairs phase.  If a wave's queue cannot hold its edges (heavily clustered boxes:
 // many true suppressions) the segment is redone by the chunked algorithm above, whose cost shrinks exactly
 // when suppressions are many.  The results are the reference's, bit for bit: the filter only ever discards
@@ -715,19 +717,25 @@ constexpr uint32_t PAIR_BIAS = 1u << 24;          // radii stay below 2^17 grid 
 // the filter, true edges, queue drains -- summed over all launches since the last reset.
 __device__ unsigned long long g_pair_stats[8];
 
-struct NmsPairLds { size_t xq, irec, orig, removed, mask, misc, wprefix, total; };
+struct NmsPairLds { size_t box, q, irec, removed, mask, misc, wprefix, total; };
 
-__host__ __device__ inline int pair_queue_cap(int blk) { return blk > 64 ? 1024 : 1024; }
+// Entries per wave queue.  A queue that fills up is drained (tested pairs leave, true edges stay at its front); the
+// segment goes to the chunked algorithm once a wave holds more than PAIR_QCAP - 64 true edges.  With 1000-box segments
+// the whole layout stays under 32 KB, so that five workgroups share a CU.
+constexpr int PAIR_QCAP = 384;
+constexpr int PAIR_RESOLVE_ROUNDS = 8;        // fixed-point rounds of the resolve before it takes the chunk-by-chunk form
 
 __host__ __device__ inline NmsPairLds nms_pair_lds(int max_seg, int n2, int blk) {
     const size_t words_cap = (size_t)((max_seg + 63) >> 6);
     NmsPairLds l;
     size_t off = 0;
-    const size_t xch = blk > 64 ? (size_t)(n2 > blk ? n2 : blk) * 8 : 0;          // sort exchange buffer, dead before the queues fill
-    const size_t queues = (size_t)(blk / 64) * pair_queue_cap(blk) * 4;
-    l.xq = off;      off += xch > queues ? xch : queues;
+    const size_t xch = blk > 64 ? (size_t)(n2 > blk ? n2 : blk) * 8 : 0;          // sort exchange buffer, dead before the boxes arrive
+    const size_t boxes = (size_t)max_seg * 16;                                    // the boxes in sorted order, for the exact test
+    l.box = off;     off += boxes > xch ? boxes : xch;
+    const size_t queues = (size_t)(blk / 64) * PAIR_QCAP * 4;
+    const size_t orig = (((size_t)max_seg * 2 + 15) & ~(size_t)15);              // sorted position -> row inside the segment, dead before the queues fill
+    l.q = off;       off += queues > orig ? queues : orig;
     l.irec = off;    off += (size_t)((max_seg + 63) & ~63) * 8 + 64;              // per box: packed centre, BIAS + radius (+ read-ahead slack)
-    l.orig = off;    off += (((size_t)max_seg * 2 + 15) & ~(size_t)15);          // sorted position -> row inside the segment
     l.removed = off; off += ((words_cap * 8 + 15) & ~(size_t)15);
     l.mask = off;    off += 64 * 8;
     l.misc = off;    off += 128;                                                 // keep word; extent reduction; edge counts; overflow flag
@@ -743,7 +751,7 @@ __device__ inline bool nms_pairs_body(
     const NmsParams &np, float2 *__restrict__ kept, int32_t *__restrict__ kcount, unsigned long long *s_dyn) {
     static_assert(JPT <= 4, "the sweep is specialised for at most four slots per wave");
     constexpr int W = BLK / 64;
-    constexpr int QCAP = 1024;
+    constexpr int QCAP = PAIR_QCAP;
     const int s = blockIdx.x, b = blockIdx.y;
     const int32_t *so = seg_off + (size_t)b * (np.S + 1);
     const int seg0 = so[s];
@@ -756,15 +764,17 @@ __device__ inline bool nms_pairs_body(
     }
     const NmsPairLds ld = nms_pair_lds(np.max_seg, np.n2, BLK);
     char *lds_base = reinterpret_cast<char *>(s_dyn);
-    unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(lds_base + ld.xq);
-    uint32_t *s_queue = reinterpret_cast<uint32_t *>(lds_base + ld.xq);
+    unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(lds_base + ld.box);
+    float4 *s_box = reinterpret_cast<float4 *>(lds_base + ld.box);
+    uint32_t *s_queue = reinterpret_cast<uint32_t *>(lds_base + ld.q);
+    uint16_t *s_orig = reinterpret_cast<uint16_t *>(lds_base + ld.q);
     uint2 *s_irec = reinterpret_cast<uint2 *>(lds_base + ld.irec);
-    uint16_t *s_orig = reinterpret_cast<uint16_t *>(lds_base + ld.orig);
     unsigned long long *s_removed = reinterpret_cast<unsigned long long *>(lds_base + ld.removed);
     unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(lds_base + ld.mask);
     float *s_red = reinterpret_cast<float *>(lds_base + ld.misc + 16);            // 4 x 4 floats
     uint32_t *s_ne = reinterpret_cast<uint32_t *>(lds_base + ld.misc + 80);       // edges per wave
     uint32_t *s_ovf = reinterpret_cast<uint32_t *>(lds_base + ld.misc + 96);
+    uint32_t *s_flag = reinterpret_cast<uint32_t *>(lds_base + ld.misc + 100);    // two words: "this round changed something"
     uint32_t *s_wprefix = reinterpret_cast<uint32_t *>(lds_base + ld.wprefix);
 
     const size_t row0 = (size_t)b * np.stride + seg0;
@@ -799,7 +809,7 @@ __device__ inline bool nms_pairs_body(
     }
     for (int i = tid; i < words; i += BLK) s_removed[i] = 0ull;
     if (tid < 64) s_mask[tid] = 0ull;
-    if (tid == 0) *s_ovf = 0u;
+    if (tid == 0) { *s_ovf = 0u; s_flag[0] = 0u; s_flag[1] = 0u; }
     __syncthreads();
     // slot m of this wave is chunk m*W + wv (even m) or m*W + W-1-wv (odd m) of the sorted order
     int pos[JPT], orig[JPT];
@@ -855,9 +865,10 @@ __device__ inline bool nms_pairs_body(
             }
         }
         if (pos[m] < ((np.max_seg + 63) & ~63)) s_irec[pos[m]] = make_uint2(c, ri);      // padding beyond n: ri = 0 passes nothing
+        if (pos[m] < n) s_box[pos[m]] = bj[m];
         cq[m] = c; nj[m] = rj;
     }
-    __syncthreads();                                      // records visible; the sort exchange buffer is dead: queues may fill
+    __syncthreads();                                      // records and boxes visible; the row table is dead: queues may fill
     const long long t_sorted = np.stats ? (long long)__builtin_readcyclecounter() : 0ll;
 
     // ---- 2b / 3. all pairs (i before j), wave-local queue
@@ -873,7 +884,7 @@ __device__ inline bool nms_pairs_body(
             if (idx < nq) {
                 e = q[idx];
                 const int i = (int)(e >> 16), j = (int)(e & 0xffffu);
-                const float4 bi = boxes[row0 + s_orig[i]], bk = boxes[row0 + s_orig[j]];
+                const float4 bi = s_box[i], bk = s_box[j];
                 const float ai = (bi.z - bi.x) * (bi.w - bi.y);
                 yes = suppresses_nodiv(bi, ai, bk, thr, k_hi, k_lo, u_min);
             }
@@ -912,18 +923,23 @@ __device__ inline bool nms_pairs_body(
                     }
                 };
                 // four records per trip, the next four already in flight (the same address in every lane: broadcast
-                // reads); records beyond n are padding that passes nothing
+                // reads); records beyond n are padding that passes nothing.  Two trips per turn of the loop, so that
+                // the two register sets swap roles without moves.
                 const uint4 *rp = reinterpret_cast<const uint4 *>(s_irec + c0 + t0);
                 uint4 ra = rp[0], rb = rp[1];
-#pragma unroll 2
-                for (int g = 0; g < 8; ++g) {
-                    rp += 2;
-                    const uint4 na = rp[0], nb = rp[1];
+#pragma unroll 1
+                for (int g = 0; g < 4; ++g) {
+                    const uint4 na = rp[2], nb = rp[3];
                     step(ra.x, ra.y);
                     step(ra.z, ra.w);
                     step(rb.x, rb.y);
                     step(rb.z, rb.w);
-                    ra = na; rb = nb;
+                    rp += 4;
+                    ra = rp[0]; rb = rp[1];
+                    step(na.x, na.y);
+                    step(na.z, na.w);
+                    step(nb.x, nb.y);
+                    step(nb.z, nb.w);
                 }
             };
             switch (m0) {
@@ -940,27 +956,31 @@ __device__ inline bool nms_pairs_body(
                 for (int m = 0; m < JPT; ++m)
                     if (m == m0) hist[m] &= keepbits;
             }
+            // every lane appends the pairs of its set bits: one prefix sum over the per-lane counts gives the places
+            uint32_t cnt = 0u;
+#pragma unroll
+            for (int m = 0; m < JPT; ++m) cnt += (uint32_t)__popc(hist[m]);
+            if (__ballot(cnt != 0u) == 0ull) continue;
+            const uint32_t inc = wave_inclusive_add(cnt);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            if (nq + total > (uint32_t)QCAP) {
+                drain();
+                ++n_drains;
+                if (ne + total > (uint32_t)QCAP) { ovf = true; break; }
+            }
+            uint32_t *qp = q + (nq + inc - cnt);
 #pragma unroll
             for (int m = 0; m < JPT; ++m) {
-                uint32_t hm = hist[m];
-                for (;;) {
-                    const unsigned long long act = __ballot(hm != 0u);
-                    if (act == 0ull || ovf) break;
-                    if (nq + 64u > (uint32_t)QCAP) {
-                        drain();
-                        ++n_drains;
-                        if (ne + 64u > (uint32_t)QCAP) { ovf = true; break; }
-                    }
-                    if (hm != 0u) {
-                        const int bit = 31 - __clz((int)hm);
-                        hm &= ~(1u << bit);
-                        q[nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u))] =
-                            ((uint32_t)(c0 + t0 + 31 - bit) << 16) | (uint32_t)pos[m];
-                    }
-                    nq += (uint32_t)__popcll(act);
-                    n_passed += (uint32_t)__popcll(act);
+                uint32_t hm = __brev(hist[m]);              // bit k: box c0 + t0 + k
+                const uint32_t tag = ((uint32_t)(c0 + t0) << 16) | (uint32_t)pos[m];
+                while (hm != 0u) {
+                    const uint32_t bit = (uint32_t)__builtin_ctz(hm);
+                    hm &= hm - 1u;
+                    *qp++ = (bit << 16) + tag;
                 }
             }
+            nq += total;
+            n_passed += total;
         }
     }
     if (!ovf) { drain(); ++n_drains; }
@@ -985,33 +1005,63 @@ __device__ inline bool nms_pairs_body(
     uint32_t nev[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) nev[w] = s_ne[w];
-    for (int ch = 0; ch < words; ++ch) {
-        const int c0 = ch << 6;
-        const int cn = min(64, n - c0);
-        const unsigned long long valid = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
+    // Box j goes iff some kept earlier box i has an edge to it.  Iterating  removed' = { j : some edge (i, j) with i not in
+    // removed }  from the empty set settles every box whose longest chain of edges has k links after k rounds, and a round
+    // that changes nothing is the greedy result (the equation has one solution: by induction over the score order).  Sparse
+    // edge lists settle in a handful of rounds of one pass over the edges each; the rest take the chunk-by-chunk resolve.
+    bool settled = false;
+    for (int it = 0; it < PAIR_RESOLVE_ROUNDS; ++it) {
+        if (tid < words) s_mask[tid] = 0ull;
+        __syncthreads();
+        if (tid == 0) s_flag[(it + 1) & 1] = 0u;           // everybody has read it (the round before) by now
 #pragma unroll
         for (int w = 0; w < W; ++w)
             for (uint32_t e = tid; e < nev[w]; e += BLK) {
                 const uint32_t en = s_queue[w * QCAP + e];
                 const int i = (int)(en >> 16), j = (int)(en & 0xffffu);
-                if ((j >> 6) != ch) continue;
-                if (i >= c0) atomicOr(&s_mask[i - c0], 1ull << (j - c0));
-                else if (!((s_removed[i >> 6] >> (i & 63)) & 1ull)) atomicOr(&s_removed[ch], 1ull << (j & 63));
+                if (!((s_removed[i >> 6] >> (i & 63)) & 1ull)) atomicOr(&s_mask[j >> 6], 1ull << (j & 63));
             }
         __syncthreads();
-        if (wv == 0) {
-            const unsigned long long m = s_mask[lane];
-            s_mask[lane] = 0ull;
-            unsigned long long rows = __ballot(m != 0ull);
-            unsigned long long keep = uniform64(~s_removed[ch] & valid);
-            while (rows) {                                   // only rows that suppress anything matter, in order
-                const int i = __ffsll((long long)rows) - 1;
-                rows &= rows - 1ull;
-                if ((keep >> i) & 1ull) keep &= ~readlane64(m, i);
-            }
-            if (lane == 0) s_removed[ch] = valid & ~keep;
+        if (tid < words) {
+            const unsigned long long next = s_mask[tid];
+            if (next != s_removed[tid]) s_flag[it & 1] = 1u;
+            s_removed[tid] = next;
         }
         __syncthreads();
+        if (s_flag[it & 1] == 0u) { settled = true; break; }
+    }
+    if (!settled) {
+        for (int i = tid; i < words; i += BLK) s_removed[i] = 0ull;
+        if (tid < 64) s_mask[tid] = 0ull;
+        __syncthreads();
+        for (int ch = 0; ch < words; ++ch) {
+            const int c0 = ch << 6;
+            const int cn = min(64, n - c0);
+            const unsigned long long valid = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+                for (uint32_t e = tid; e < nev[w]; e += BLK) {
+                    const uint32_t en = s_queue[w * QCAP + e];
+                    const int i = (int)(en >> 16), j = (int)(en & 0xffffu);
+                    if ((j >> 6) != ch) continue;
+                    if (i >= c0) atomicOr(&s_mask[i - c0], 1ull << (j - c0));
+                    else if (!((s_removed[i >> 6] >> (i & 63)) & 1ull)) atomicOr(&s_removed[ch], 1ull << (j & 63));
+                }
+            __syncthreads();
+            if (wv == 0) {
+                const unsigned long long m = s_mask[lane];
+                s_mask[lane] = 0ull;
+                unsigned long long rows = __ballot(m != 0ull);
+                unsigned long long keep = uniform64(~s_removed[ch] & valid);
+                while (rows) {                                   // only rows that suppress anything matter, in order
+                    const int i = __ffsll((long long)rows) - 1;
+                    rows &= rows - 1ull;
+                    if ((keep >> i) & 1ull) keep &= ~readlane64(m, i);
+                }
+                if (lane == 0) s_removed[ch] = valid & ~keep;
+            }
+            __syncthreads();
+        }
     }
     // kept = not removed; compact in sorted order
     if (wv == 0) {

@@ -547,20 +547,6 @@ __global__ __launch_bounds__(BLK) void select_plan_kernel(const float *__restric
     if (tid == 0) rules[(size_t)b * sp.Cs + ci] = r;
 }
 
-// Inclusive prefix sum over the 64 lanes with data-parallel-primitive moves: shifts inside the rows of 16, then the row
-// totals are broadcast into the following rows.  Every lane of the wave must be active.
-__device__ inline uint32_t wave_inclusive_add(uint32_t v) {
-#define DETBOX_DPP_ADD(ctrl, rows) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, false)
-    DETBOX_DPP_ADD(0x111, 0xf);     // row_shr:1
-    DETBOX_DPP_ADD(0x112, 0xf);     // row_shr:2
-    DETBOX_DPP_ADD(0x114, 0xf);     // row_shr:4
-    DETBOX_DPP_ADD(0x118, 0xf);     // row_shr:8
-    DETBOX_DPP_ADD(0x142, 0xa);     // row_bcast:15 into rows 1 and 3
-    DETBOX_DPP_ADD(0x143, 0xc);     // row_bcast:31 into rows 2 and 3
-#undef DETBOX_DPP_ADD
-    return v;
-}
-
 // Staged candidate as the scan writes it: score key (32) | class slot (8) | anchor (24).
 __device__ inline unsigned long long pack_entry(uint32_t d, uint32_t ci, uint32_t p) {
     return ((unsigned long long)d << 32) | ((unsigned long long)ci << 24) | (unsigned long long)p;

@@ -708,6 +708,13 @@ def test_nms_pair_list_and_its_fall_back(D, oracle, dev):
         wh = 0.2 + 0.01 * torch.rand(n, 2, generator=g)
         st = run(torch.cat([c - wh / 2, c + wh / 2], 1), torch.rand(n, generator=g), idxs)
         assert st[0] == 3 and st[1] == 3                                # every segment overflowed and was redone
+        # a staircase: a box overlaps its two neighbours only, so whether it stays depends on the whole chain before it
+        # (in score order): chains of 600 links, of one link, and whatever random scores make of them
+        k = torch.arange(600, dtype=torch.float32)
+        stairs = torch.stack([0.3 * k, 0 * k, 0.3 * k + 1, 0 * k + 1], 1)
+        for sc in (-k, k, (k % 2) + 0.001 * k, torch.rand(600, generator=g)):
+            st = run(stairs, sc, torch.zeros(600, dtype=torch.long))
+            assert st[0] == 1 and st[1] == 0 and st[3] == 599
     finally:
         L.detbox_debug_nms_stats_enable(0)
 
