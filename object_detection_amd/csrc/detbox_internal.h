@@ -101,4 +101,26 @@ __device__ inline uint32_t wave_inclusive_add(uint32_t v) {
     return v;
 }
 
+// Value of lane (lane ^ J) for every lane.  Distances inside a row of 16 lanes are data-parallel-primitive moves in the
+// VALU (1, 2: quad permutations; 4: the two shifts by four, each kept in the quads it is right for; 8: a rotation of the
+// row by eight); 16 and 32 cross rows and go through the LDS crossbar.
+template <int J>
+__device__ inline uint32_t lane_xor_u32(const uint32_t v) {
+    if constexpr (J == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);      // quad_perm:[1,0,3,2]
+    else if constexpr (J == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true); // quad_perm:[2,3,0,1]
+    else if constexpr (J == 4) {
+        const int up = __builtin_amdgcn_mov_dpp((int)v, 0x104, 0xf, 0x5, true);                             // row_shl:4 into quads 0 and 2
+        return (uint32_t)__builtin_amdgcn_update_dpp(up, (int)v, 0x114, 0xf, 0xa, false);                       // row_shr:4 into quads 1 and 3
+    } else if constexpr (J == 8) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xf, 0xf, true); // row_ror:8
+    else return (uint32_t)__shfl_xor((int)v, J);
+}
+
+template <int J>
+__device__ inline unsigned long long lane_xor_u64(const unsigned long long v) {
+    return ((unsigned long long)lane_xor_u32<J>((uint32_t)(v >> 32)) << 32) | lane_xor_u32<J>((uint32_t)v);
+}
+
+template <int J>
+__device__ inline float lane_xor_f32(const float v) { return __uint_as_float(lane_xor_u32<J>(__float_as_uint(v))); }
+
 }  // namespace detbox

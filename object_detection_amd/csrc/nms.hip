@@ -88,40 +88,48 @@ __device__ inline void bitonic_desc_u64(unsigned long long *s, int n) {
 // thread tid.  Strides >= 256 are exchanges between registers of one thread, strides < 64 are wave
 // shuffles; only strides 64 and 128 go through LDS (`xch`, 256*R keys) and need barriers.  Keys at
 // e >= n2 must be zero: only the passes up to n2 run and they never move a key across an n2 boundary.
+// One compare-exchange pass at distance J of the stage that builds sorted runs of KK keys, then the passes below it.
+template <int R, int KK, int J, int BLK>
+__device__ inline void bitonic_pass_u64(unsigned long long (&K)[R], unsigned long long *xch, const int tid) {
+    if constexpr (J >= BLK) {
+        constexpr int dm = J / BLK;
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            const int pm = m ^ dm;
+            if (pm > m) {
+                const unsigned long long a = K[m], c = K[pm];
+                const bool desc = ((m * BLK) & KK) == 0;           // KK >= 2*BLK here: the bit lies in m
+                const bool swap = (a > c) != desc && a != c;
+                K[m] = swap ? c : a;
+                K[pm] = swap ? a : c;
+            }
+        }
+    } else {
+        if constexpr (J >= 64) {
+#pragma unroll
+            for (int m = 0; m < R; ++m) xch[m * BLK + tid] = K[m];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            const int e = m * BLK + tid;
+            const unsigned long long a = K[m];
+            unsigned long long c;
+            if constexpr (J >= 64) c = xch[e ^ J];
+            else c = lane_xor_u64<J>(a);
+            const bool lower = (tid & J) == 0;
+            const bool desc = (e & KK) == 0;
+            // the lower element of a descending pair keeps the larger key: one compare, one select per word
+            K[m] = ((a > c) == (lower == desc)) ? a : c;
+        }
+        if constexpr (J >= 64) __syncthreads();
+    }
+    if constexpr (J > 1) bitonic_pass_u64<R, KK, J / 2, BLK>(K, xch, tid);
+}
+
 template <int R, int KK, int BLK>
 __device__ inline void bitonic_stage_u64(unsigned long long (&K)[R], unsigned long long *xch, const int tid) {
-#pragma unroll
-    for (int j = KK >> 1; j > 0; j >>= 1) {
-        if (j >= BLK) {
-            const int dm = j / BLK;
-#pragma unroll
-            for (int m = 0; m < R; ++m) {
-                const int pm = m ^ dm;
-                if (pm > m) {
-                    const unsigned long long a = K[m], c = K[pm];
-                    const bool desc = ((m * BLK) & KK) == 0;           // KK >= 2*BLK here: the bit lies in m
-                    if (desc ? (a < c) : (a > c)) { K[m] = c; K[pm] = a; }
-                }
-            }
-        } else {
-            if (j >= 64) {
-#pragma unroll
-                for (int m = 0; m < R; ++m) xch[m * BLK + tid] = K[m];
-                __syncthreads();
-            }
-#pragma unroll
-            for (int m = 0; m < R; ++m) {
-                const int e = m * BLK + tid;
-                const unsigned long long a = K[m];
-                const unsigned long long c = j >= 64 ? xch[e ^ j] : __shfl_xor(a, j);
-                const bool lower = (tid & j) == 0;
-                const bool desc = (e & KK) == 0;
-                const unsigned long long mx = a > c ? a : c, mn = a > c ? c : a;
-                K[m] = (lower == desc) ? mx : mn;
-            }
-            if (j >= 64) __syncthreads();
-        }
-    }
+    bitonic_pass_u64<R, KK, KK / 2, BLK>(K, xch, tid);
 }
 
 template <int R, int KK, int BLK>

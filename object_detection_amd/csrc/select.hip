@@ -93,16 +93,19 @@ __device__ inline unsigned long long make_key(float s, uint32_t key_thr, uint32_
 // Activation of one sub-tile: rows x C head outputs -> scores, four lanes per anchor row.
 // ---------------------------------------------------------------------------------------------
 
-__device__ inline float quad_max(float v) {          // over the LPR lanes of a row
-#pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+// Reductions over the LPR lanes of a row: in-row moves of the VALU, nothing goes through the LDS crossbar.
+template <int O>
+__device__ inline float quad_max_from(float v) {
+    if constexpr (O < LPR) return quad_max_from<O * 2>(fmaxf(v, lane_xor_f32<O>(v)));
+    else return v;
 }
-__device__ inline float quad_sum(float v) {
-#pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o);
-    return v;
+template <int O>
+__device__ inline float quad_sum_from(float v) {
+    if constexpr (O < LPR) return quad_sum_from<O * 2>(v + lane_xor_f32<O>(v));
+    else return v;
 }
+__device__ inline float quad_max(float v) { return quad_max_from<1>(v); }
+__device__ inline float quad_sum(float v) { return quad_sum_from<1>(v); }
 __device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // One sub-tile = rows [row_base, row_base+rows) x C of the head output.  It is brought into LDS by
