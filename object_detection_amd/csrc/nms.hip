@@ -152,6 +152,14 @@ __device__ inline void bitonic_desc_u64_regs(unsigned long long (&K)[R], unsigne
     bitonic_stages_u64<R, 2, BLK>(K, xch, n2, tid);
 }
 
+// Minimum of lx, ly and maximum of hx, hy over the wave, left in every lane.
+template <int O>
+__device__ inline void wave_extent(float &lx, float &ly, float &hx, float &hy) {
+    lx = fminf(lx, lane_xor_f32<O>(lx)); ly = fminf(ly, lane_xor_f32<O>(ly));
+    hx = fmaxf(hx, lane_xor_f32<O>(hx)); hy = fmaxf(hy, lane_xor_f32<O>(hy));
+    if constexpr (O > 1) wave_extent<O / 2>(lx, ly, hx, hy);
+}
+
 __device__ inline unsigned long long uniform64(unsigned long long v) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -287,14 +295,9 @@ __global__ __launch_bounds__(NMS_BLOCK) void nms_segments_generic_kernel(
                 const unsigned long long valid = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
                 pc = (uint32_t)__popcll(~s_removed[w] & valid);
             }
-            uint32_t inc = pc;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t up = __shfl_up(inc, o);
-                if (lane >= o) inc += up;
-            }
+            const uint32_t inc = wave_inclusive_add(pc);
             if (w < words) s_wprefix[w] = running + inc - pc;
-            running += __shfl(inc, 63);
+            running += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         }
         if (lane == 0) kcount[(size_t)b * np.S + s] = (int32_t)running;
     }
@@ -471,11 +474,7 @@ __device__ inline void nms_chunked_body(
     }
     for (int i = tid; i < words; i += BLK) s_removed[i] = 0ull;
     if (tid < 64) s_mask[tid] = 0ull;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        lx = fminf(lx, __shfl_xor(lx, o)); ly = fminf(ly, __shfl_xor(ly, o));
-        hx = fmaxf(hx, __shfl_xor(hx, o)); hy = fmaxf(hy, __shfl_xor(hy, o));
-    }
+    wave_extent<32>(lx, ly, hx, hy);
     if (lane == 0) { s_red[wv * 4 + 0] = lx; s_red[wv * 4 + 1] = ly; s_red[wv * 4 + 2] = hx; s_red[wv * 4 + 3] = hy; }
     __syncthreads();
     lx = s_red[0]; ly = s_red[1]; hx = s_red[2]; hy = s_red[3];
@@ -655,14 +654,9 @@ __device__ inline void nms_chunked_body(
                 const unsigned long long valid = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
                 pc = (uint32_t)__popcll(~s_removed[w] & valid);
             }
-            uint32_t inc = pc;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t up = __shfl_up(inc, o);
-                if (lane >= o) inc += up;
-            }
+            const uint32_t inc = wave_inclusive_add(pc);
             if (w < words) s_wprefix[w] = running + inc - pc;
-            running += __shfl(inc, 63);
+            running += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         }
         if (lane == 0) kcount[(size_t)b * np.S + s] = (int32_t)running;
     }
@@ -835,11 +829,7 @@ __device__ inline bool nms_pairs_body(
             lx = fminf(lx, bj[m].x); ly = fminf(ly, bj[m].y); hx = fmaxf(hx, bj[m].z); hy = fmaxf(hy, bj[m].w);
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        lx = fminf(lx, __shfl_xor(lx, o)); ly = fminf(ly, __shfl_xor(ly, o));
-        hx = fmaxf(hx, __shfl_xor(hx, o)); hy = fmaxf(hy, __shfl_xor(hy, o));
-    }
+    wave_extent<32>(lx, ly, hx, hy);
     if (lane == 0) { s_red[wv * 4 + 0] = lx; s_red[wv * 4 + 1] = ly; s_red[wv * 4 + 2] = hx; s_red[wv * 4 + 3] = hy; }
     __syncthreads();
     lx = s_red[0]; ly = s_red[1]; hx = s_red[2]; hy = s_red[3];
@@ -1082,14 +1072,9 @@ __device__ inline bool nms_pairs_body(
                 const unsigned long long valid = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
                 pc = (uint32_t)__popcll(~s_removed[w] & valid);
             }
-            uint32_t inc = pc;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t up = __shfl_up(inc, o);
-                if (lane >= o) inc += up;
-            }
+            const uint32_t inc = wave_inclusive_add(pc);
             if (w < words) s_wprefix[w] = running + inc - pc;
-            running += __shfl(inc, 63);
+            running += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         }
         if (lane == 0) kcount[(size_t)b * np.S + s] = (int32_t)running;
     }

@@ -49,12 +49,8 @@ __global__ __launch_bounds__(RANK_BLOCK) void topk_mask_kernel(const float *__re
         if (tid < 64) {                                         // highest digit d with count(digits >= d) >= rem
             const uint4 q = reinterpret_cast<const uint4 *>(s_h)[lane];       // bins 4*lane .. 4*lane+3
             const uint32_t t = q.x + q.y + q.z + q.w;
-            uint32_t suf = t;                                                  // suffix sum over lanes >= lane
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t up = __shfl_down(suf, o);
-                if (lane + o < 64) suf += up;
-            }
+            const uint32_t inc = wave_inclusive_add(t);                        // suffix sum over lanes >= lane
+            const uint32_t suf = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63) - inc + t;
             const uint32_t rem = s_rem;
             const unsigned long long ge = __ballot(suf >= rem);
             const int L = 63 - __clzll((long long)ge);                         // the lane whose bins hold the answer

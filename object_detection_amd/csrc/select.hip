@@ -409,13 +409,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_sample_kernel(const float *
 
 // Suffix sums of a 256-bin histogram row held four bins per lane; returns the lane's suffix sum.
 __device__ inline uint32_t suffix_scan64(uint32_t t, int lane) {
-    uint32_t suf = t;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = __shfl_down(suf, o);
-        if (lane + o < 64) suf += up;
-    }
-    return suf;
+    (void)lane;
+    const uint32_t inc = wave_inclusive_add(t);                   // whole wave active
+    return (uint32_t)__builtin_amdgcn_readlane((int)inc, 63) - inc + t;
 }
 
 // Finds the highest bin beta with count(bins >= beta) >= k.  Needs total >= k.  All lanes return the same.
@@ -433,7 +429,9 @@ __device__ inline void find_kth_bin(uint4 q, uint32_t suf, uint32_t t, int lane,
             acc += hb[i];
         }
     }
-    beta = __shfl(b_, L); n_above = __shfl(a_, L); n_beta = __shfl(nb_, L);
+    beta = (uint32_t)__builtin_amdgcn_readlane((int)b_, L);      // L is the same in every lane
+    n_above = (uint32_t)__builtin_amdgcn_readlane((int)a_, L);
+    n_beta = (uint32_t)__builtin_amdgcn_readlane((int)nb_, L);
 }
 
 // Per (image, class): the sample_m-th largest sampled score, found exactly by a 4-round radix search
@@ -840,7 +838,7 @@ __global__ __launch_bounds__(256) void select_kth_kernel(const uint32_t *__restr
         const uint4 q = reinterpret_cast<const uint4 *>(h)[lane];       // bins 4*lane .. 4*lane+3
         const uint32_t t = q.x + q.y + q.z + q.w;
         const uint32_t suf = suffix_scan64(t, lane);
-        const uint32_t total = __shfl(suf, 0);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)suf);
         SelRule r;
         r.pad = 0; r.cutoff = 0ull; r.beta = 0; r.n_above = 0;
         if (total <= k) {
@@ -1118,12 +1116,7 @@ __global__ __launch_bounds__(BLK) void select_finalize_kernel(
         const int w0 = tid * wpt, w1 = min(words, w0 + wpt);
         uint32_t local = 0;
         for (int w = w0; w < w1; ++w) local += (uint32_t)__popcll(s_bm[w]);
-        uint32_t inc = local;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = __shfl_up(inc, o);
-            if (lane >= o) inc += up;
-        }
+        const uint32_t inc = wave_inclusive_add(local);
         if (lane == 63) s_wsum[wave] = inc;
         __syncthreads();
         uint32_t base = inc - local;
