@@ -385,6 +385,22 @@ def price(wl, m, world, steps):
                          frac=a / HBM_PEAK_GBS, traffic=measured_traffic(wl.name, wl.regime, 'select_scan'),
                          avg_us=kern['select_scan']['avg_us'], algorithmic_bytes=score_bytes,
                          note='survey pass: every kernel bracketed by events')
+    # the greedy NMS next to it, priced the same way whichever of the two kernels happened to be the longer one in
+    # the survey pass (they are within a few percent of each other on the dense workload)
+    pairs = None
+    if 'nms_segments' in kern:
+        us = kern['nms_segments']['avg_us']
+        a = alg_bytes['nms_segments'] / (us * 1e-6) / 1e9
+        pairs = dict(kernel='nms_segments', bound='valu', achieved=a, peak=HBM_PEAK_GBS, unit='GB/s', frac=a / HBM_PEAK_GBS,
+                     traffic=measured_traffic(wl.name, wl.regime, 'nms_segments'), avg_us=us,
+                     algorithmic_bytes=alg_bytes['nms_segments'],
+                     note='survey pass; O(n * kept) pair tests on data that stays on chip: HBM frac is reported for '
+                          'completeness, valu_frac (VALU wave-instructions x 4 cycles / (SIMDs x kernel cycles), '
+                          'committed counter pass) is the yardstick')
+        v = measured_valu(wl.name, wl.regime)
+        if v is not None:
+            pairs['valu_frac'] = v['valu_insts_per_launch'] * 4.0 / (v['simds'] * v['clock_mhz'] * us)
+            pairs['valu_insts_per_launch'] = v['valu_insts_per_launch']
     anchor_bytes = {'fcos': 8, 'yolo': 20}.get(wl.w['family'], 16)
     bytes_img = ((52.0 if wl.w['family'] == 'fcos' else 48.0) * P + 24.0 * G_mean
                  + 4.0 * P * C + 16.0 * P + anchor_bytes * P + (4.0 * P if wl.ext is not None else 0.0) + 28.0 * n_cand
@@ -392,7 +408,7 @@ def price(wl, m, world, steps):
     ts = sorted(m['times'])
     med = ts[len(ts) // 2]
     ips = world * B * steps / med
-    return dict(ips=ips, ms_per_step=1e3 * med / steps, roofline=roofline, streaming=streaming, bytes_img=bytes_img,
+    return dict(ips=ips, ms_per_step=1e3 * med / steps, roofline=roofline, streaming=streaming, pairs=pairs, bytes_img=bytes_img,
                 hbm_frac=bytes_img * ips / world / (HBM_PEAK_GBS * 1e9),
                 blocks=dict(n=len(ts), steps_each=steps, ms_per_step_min=1e3 * ts[0] / steps, ms_per_step_median=1e3 * med / steps,
                             ms_per_step_max=1e3 * ts[-1] / steps),
@@ -490,6 +506,7 @@ def main():
             'blocks': pr['blocks'],
             'roofline': pr['roofline'],
             'roofline_streaming': pr['streaming'],
+            'roofline_nms': pr['pairs'],
             'cpu_baseline': cpu,
             'pipeline': {'algorithmic_bytes_per_image': pr['bytes_img'], 'hbm_frac_whole_step': pr['hbm_frac'],
                          'launches_per_step': pr['launches_per_step'], 'sub30_us_kernels_total_us': round(pr['sub30_us_total'], 1)},
