@@ -1497,7 +1497,17 @@ SelPlan make_plan(int64_t B, int64_t P, int64_t C, int64_t Cs, int top_k) {
         return sp;
     }
     static const int rate_big = [] { const char *e = std::getenv("DETBOX_SAMPLE_RATE"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 32; }();
-    int rate = P >= 65536 ? rate_big : (P >= 16384 ? 8 : 4);
+    // Staging capacity a sampling rate asks for: the m-th largest of the samples is the threshold, the true top-k clears
+    // it with z standard deviations to spare, and the list must hold everything above it.
+    auto cap_at = [&](int r) {
+        const double kr = (double)top_k / r;
+        const double sq = 0.5 * (z + std::sqrt(z * z + 4.0 * kr));
+        const int m = (int)std::ceil(sq * sq);
+        return pow2_ge((long long)((double)m * r + z * r * std::sqrt((double)m)) + 64);
+    };
+    // Below 16384 anchors every fourth sub-tile is sampled, or every eighth where that asks for no larger a staging
+    // list: the sample pass and the planning halve (SSD300 at batch 512: +7 % images/s dense, +13 % trained-like).
+    int rate = P >= 65536 ? rate_big : (P >= 16384 || cap_at(8) <= (cap_at(4) < 512 ? 512 : cap_at(4)) ? 8 : 4);
     double upper = 0.0;
     for (;;) {
         const double kr = (double)top_k / rate;
