@@ -477,7 +477,8 @@ def main():
             # graph replay where the host's launch rate is what binds (issuing a stage twice costs more than the
             # stage's kernels take: tools/twice.sh): the small workload and the trained-like regime
             for name, regime, steps, graph in (('ssd300', 'dense', 200, True), ('ssd300_b512', 'dense', 20, False),
-                                               ('retinanet800', 'trained', 50, True), ('ssd300_b512', 'trained', 50, True)):
+                                               ('retinanet800', 'trained', 50, True), ('ssd300_b512', 'trained', 50, True),
+                                               ('fcos800', 'dense', 100, True), ('yolov3', 'dense', 100, True)):
                 if name == args.workload and regime == args.regime:
                     continue
                 w2 = Workload(name, regime, 0, dev)
