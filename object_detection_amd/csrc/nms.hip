@@ -719,12 +719,20 @@ constexpr uint32_t PAIR_BIAS = 1u << 24;          // radii stay below 2^17 grid 
 // the filter, true edges, queue drains -- summed over all launches since the last reset.
 __device__ unsigned long long g_pair_stats[8];
 
-struct NmsPairLds { size_t box, q, irec, removed, mask, misc, wprefix, total; };
+struct NmsPairLds { size_t box, q, irec, removed, mask, misc, wprefix, rank, win, total; };
 
 // Entries per wave queue.  A queue that fills up is drained (tested pairs leave, true edges stay at its front); the
 // segment goes to the chunked algorithm once a wave holds more than PAIR_QCAP - 64 true edges.  With 1000-box segments
 // the whole layout stays under 32 KB, so that five workgroups share a CU.
-constexpr int PAIR_QCAP = 384;
+constexpr int PAIR_QCAP = 256;
+// Spatial order of the all-pairs phase: boxes are binned by size class and by the row of their centre (a counting sort:
+// one bin for the large boxes, 256 rows each for the medium and the small ones), so that 32 consecutive boxes share a
+// narrow band of the image and whole windows of pairs are skipped by their bounding intervals.
+constexpr int PAIR_BINS = 513;
+static_assert(PAIR_BINS <= 576, "bins");
+constexpr int PAIR_BINS_PAD = 576;           // nine bins per lane of the wave that turns the counts into offsets
+constexpr uint32_t PAIR_R_MEDIUM = 1024u;    // radii (grid units of the 15-bit grid) from which a box is medium / large
+constexpr uint32_t PAIR_R_LARGE = 4096u;
 constexpr int PAIR_RESOLVE_ROUNDS = 8;        // fixed-point rounds of the resolve before it takes the chunk-by-chunk form
 
 __host__ __device__ inline NmsPairLds nms_pair_lds(int max_seg, int n2, int blk) {
@@ -735,13 +743,16 @@ __host__ __device__ inline NmsPairLds nms_pair_lds(int max_seg, int n2, int blk)
     const size_t boxes = (size_t)max_seg * 16;                                    // the boxes in sorted order, for the exact test
     l.box = off;     off += boxes > xch ? boxes : xch;
     const size_t queues = (size_t)(blk / 64) * PAIR_QCAP * 4;
-    const size_t orig = (((size_t)max_seg * 2 + 15) & ~(size_t)15);              // sorted position -> row inside the segment, dead before the queues fill
+    // rank -> row inside the segment (2048 bytes: at most 1024 boxes), then the bins of the counting sort; both dead before the queues fill
+    const size_t orig = blk > 64 ? 2048 + (size_t)PAIR_BINS_PAD * 4 : (((size_t)max_seg * 2 + 15) & ~(size_t)15);
     l.q = off;       off += queues > orig ? queues : orig;
     l.irec = off;    off += (size_t)((max_seg + 63) & ~63) * 8 + 64;              // per box: packed centre, BIAS + radius (+ read-ahead slack)
     l.removed = off; off += ((words_cap * 8 + 15) & ~(size_t)15);
     l.mask = off;    off += 64 * 8;
     l.misc = off;    off += 128;                                                 // keep word; extent reduction; edge counts; overflow flag
     l.wprefix = off; off += ((words_cap * 4 + 15) & ~(size_t)15);
+    l.rank = off;    off += blk > 64 ? (((size_t)max_seg * 2 + 15) & ~(size_t)15) : 0;   // spatial position -> rank in score order
+    l.win = off;     off += blk > 64 ? 32 * 16 : 0;                                     // bounding intervals of the 32-box windows
     l.total = off;
     return l;
 }
@@ -754,6 +765,9 @@ __device__ inline bool nms_pairs_body(
     static_assert(JPT <= 4, "the sweep is specialised for at most four slots per wave");
     constexpr int W = BLK / 64;
     constexpr int QCAP = PAIR_QCAP;
+    // The four-wave form (up to 1024 boxes) orders the boxes spatially for the all-pairs phase; the single-wave form (up to
+    // 256 boxes: at most eight windows) keeps the score order, where the re-ordering would cost more than it skips.
+    constexpr bool SPATIAL = BLK > 64;
     const int s = blockIdx.x, b = blockIdx.y;
     const int32_t *so = seg_off + (size_t)b * (np.S + 1);
     const int seg0 = so[s];
@@ -778,6 +792,9 @@ __device__ inline bool nms_pairs_body(
     uint32_t *s_ovf = reinterpret_cast<uint32_t *>(lds_base + ld.misc + 96);
     uint32_t *s_flag = reinterpret_cast<uint32_t *>(lds_base + ld.misc + 100);    // two words: "this round changed something"
     uint32_t *s_wprefix = reinterpret_cast<uint32_t *>(lds_base + ld.wprefix);
+    uint32_t *s_bin = reinterpret_cast<uint32_t *>(lds_base + ld.q + 2048);
+    uint16_t *s_rank = reinterpret_cast<uint16_t *>(lds_base + ld.rank);
+    float4 *s_win = reinterpret_cast<float4 *>(lds_base + ld.win);
 
     const size_t row0 = (size_t)b * np.stride + seg0;
     const int tid = threadIdx.x;
@@ -812,21 +829,22 @@ __device__ inline bool nms_pairs_body(
     for (int i = tid; i < words; i += BLK) s_removed[i] = 0ull;
     if (tid < 64) s_mask[tid] = 0ull;
     if (tid == 0) { *s_ovf = 0u; s_flag[0] = 0u; s_flag[1] = 0u; }
+    if (SPATIAL)
+        for (int i = tid; i < PAIR_BINS_PAD; i += BLK) s_bin[i] = 0u;
     __syncthreads();
-    // slot m of this wave is chunk m*W + wv (even m) or m*W + W-1-wv (odd m) of the sorted order
-    int pos[JPT], orig[JPT];
-    float4 bj[JPT];
+    // this thread's boxes, for the records and (at the very end) for the output: ranks tid, tid + BLK, ... of the score order
+    int orig[JPT];
+    float4 ba[JPT];
     float lx = __builtin_inff(), ly = __builtin_inff(), hx = -__builtin_inff(), hy = -__builtin_inff();
 #pragma unroll
     for (int m = 0; m < JPT; ++m) {
-        const int ch = m * W + ((m & 1) ? (W - 1 - wv) : wv);
-        pos[m] = (ch << 6) + lane;
-        bj[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int rk = tid + m * BLK;
+        ba[m] = make_float4(0.f, 0.f, 0.f, 0.f);
         orig[m] = 0;
-        if (pos[m] < n) {
-            orig[m] = (int)s_orig[pos[m]];
-            bj[m] = boxes[row0 + orig[m]];
-            lx = fminf(lx, bj[m].x); ly = fminf(ly, bj[m].y); hx = fmaxf(hx, bj[m].z); hy = fmaxf(hy, bj[m].w);
+        if (rk < n) {
+            orig[m] = (int)s_orig[rk];
+            ba[m] = boxes[row0 + orig[m]];
+            lx = fminf(lx, ba[m].x); ly = fminf(ly, ba[m].y); hx = fmaxf(hx, ba[m].z); hy = fmaxf(hy, ba[m].w);
         }
     }
     wave_extent<32>(lx, ly, hx, hy);
@@ -845,28 +863,83 @@ __device__ inline bool nms_pairs_body(
     const float scale = q_ok ? Q_MAX / E : 0.0f;
     const float thr_q = thr * 0.999f;
     const float two_t = fminf(2.0f * thr_q / (1.0f + thr_q), 1.0f);      // 2 * thr / (1 + thr), at most 1
-    uint32_t cq[JPT], nj[JPT];                            // packed centre; BIAS - radius (j role)
+    // A box's record: packed centre, BIAS + radius.  In the j role the same box enters as BIAS - radius, which is
+    // 2 * BIAS - (BIAS + radius); a box without positive width and height has the record (0, 0) and meets nobody in
+    // either role.  Bins of the spatial order: 0 for the large boxes, then 256 rows of medium and 256 rows of small ones.
+    uint32_t c_a[JPT], ri_a[JPT], place_a[JPT];
 #pragma unroll
     for (int m = 0; m < JPT; ++m) {
-        const float w = bj[m].z - bj[m].x, h = bj[m].w - bj[m].y;
-        uint32_t c = 0u, ri = 0u, rj = 2u * PAIR_BIAS;      // a box without positive width and height meets nobody
-        if (pos[m] < n) {
-            if (!q_ok) { ri = PAIR_BIAS; rj = 0u; }        // passes every real box (never the padding beyond n)
+        const int rk = tid + m * BLK;
+        const float w = ba[m].z - ba[m].x, h = ba[m].w - ba[m].y;
+        uint32_t c = 0u, ri = 0u, bin = 0u, place = 0u;
+        if (rk < n) {
+            if (!q_ok) ri = PAIR_BIAS;                     // radius 0 on a grid of one point: passes every real box
             else if (w > 0.0f && h > 0.0f) {
-                const float fx = rintf(((bj[m].x + bj[m].z) * 0.5f - lx) * scale), fy = rintf(((bj[m].y + bj[m].w) * 0.5f - ly) * scale);
+                const float fx = rintf(((ba[m].x + ba[m].z) * 0.5f - lx) * scale), fy = rintf(((ba[m].y + ba[m].w) * 0.5f - ly) * scale);
                 const uint32_t x = (uint32_t)fminf(fmaxf(fx, 0.0f), Q_MAX), y = (uint32_t)fminf(fmaxf(fy, 0.0f), Q_MAX);
                 c = (y << 16) | x;
                 // rounding of the two centres moves |dcx| + |dcy| by at most 2 grid units (+ fp32 slop): 1.25 per box
                 const float rad = fmaxf((w + h) * 0.5f - sqrtf(two_t * w * h), 0.0f) * 1.001f * scale;
                 const uint32_t r = (uint32_t)fminf(ceilf(rad + 1.25f), 131000.0f);
-                ri = PAIR_BIAS + r; rj = PAIR_BIAS - r;
+                ri = PAIR_BIAS + r;
+                if (r < PAIR_R_LARGE) bin = (r >= PAIR_R_MEDIUM ? 1u : 257u) + (y >> 7);
             }
+            if (SPATIAL) place = atomicAdd(&s_bin[bin], 1u);             // place inside the bin, in no particular order
         }
-        if (pos[m] < ((np.max_seg + 63) & ~63)) s_irec[pos[m]] = make_uint2(c, ri);      // padding beyond n: ri = 0 passes nothing
-        if (pos[m] < n) s_box[pos[m]] = bj[m];
-        cq[m] = c; nj[m] = rj;
+        c_a[m] = c; ri_a[m] = ri;
+        place_a[m] = (bin << 16) | place;
     }
-    __syncthreads();                                      // records and boxes visible; the row table is dead: queues may fill
+    if (SPATIAL) {
+        __syncthreads();
+        if (wv == 0) {                                          // bin counts -> bin offsets, nine bins per lane
+            uint32_t cnts[9], sum = 0u;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { cnts[k] = s_bin[lane * 9 + k]; sum += cnts[k]; }
+            uint32_t run = wave_inclusive_add(sum) - sum;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { s_bin[lane * 9 + k] = run; run += cnts[k]; }
+        }
+    }
+    __syncthreads();                                          // (single-wave form: everybody has read the row table)
+    // records, boxes and ranks by spatial position (the sort buffer is dead: the boxes may land); padding behind them
+    const int cap_pos = (np.max_seg + 63) & ~63;
+#pragma unroll
+    for (int m = 0; m < JPT; ++m) {
+        const int rk = tid + m * BLK;
+        if (rk < n) {
+            const uint32_t sp = SPATIAL ? s_bin[place_a[m] >> 16] + (place_a[m] & 0xffffu) : (uint32_t)rk;
+            s_irec[sp] = make_uint2(c_a[m], ri_a[m]);
+            s_box[sp] = ba[m];
+            if (SPATIAL) s_rank[sp] = (uint16_t)rk;
+        }
+    }
+    for (int i = n + tid; i < cap_pos; i += BLK) s_irec[i] = make_uint2(0u, 0u);
+    __syncthreads();                                      // records and boxes visible; the row table and the bins are dead: queues may fill
+    // slot m of this wave is chunk m*W + wv (even m) or m*W + W-1-wv (odd m) of the spatial order
+    int pos[JPT];
+    uint32_t cq[JPT], nj[JPT];                            // packed centre; BIAS - radius (j role)
+    float sb_lx[JPT], sb_ly[JPT], sb_hx[JPT], sb_hy[JPT];  // wave-uniform: bounding intervals of the slot's centres -+ radii
+#pragma unroll
+    for (int m = 0; m < JPT; ++m) {
+        const int ch = m * W + ((m & 1) ? (W - 1 - wv) : wv);
+        pos[m] = (ch << 6) + lane;
+        uint2 rec = make_uint2(0u, 0u);
+        if (pos[m] < cap_pos) rec = s_irec[pos[m]];
+        cq[m] = rec.x; nj[m] = 2u * PAIR_BIAS - rec.y;
+        sb_lx[m] = 0.f; sb_ly[m] = 0.f; sb_hx[m] = 0.f; sb_hy[m] = 0.f;
+        if (!SPATIAL) continue;
+        float x0 = __builtin_inff(), y0 = __builtin_inff(), x1 = -__builtin_inff(), y1 = -__builtin_inff();
+        if (rec.y >= PAIR_BIAS) {
+            const float r = (float)(rec.y - PAIR_BIAS), cx = (float)(rec.x & 0xffffu), cy = (float)(rec.x >> 16);
+            x0 = cx - r; x1 = cx + r; y0 = cy - r; y1 = cy + r;
+        }
+        wave_extent<16>(x0, y0, x1, y1);                    // the two windows of 32 boxes of this chunk
+        if ((lane & 31) == 0 && ch < 16) s_win[2 * ch + (lane >> 5)] = make_float4(x0, y0, x1, y1);
+        x0 = fminf(x0, lane_xor_f32<32>(x0)); y0 = fminf(y0, lane_xor_f32<32>(y0));
+        x1 = fmaxf(x1, lane_xor_f32<32>(x1)); y1 = fmaxf(y1, lane_xor_f32<32>(y1));
+        sb_lx[m] = readlane_f(x0, 0); sb_ly[m] = readlane_f(y0, 0); sb_hx[m] = readlane_f(x1, 0); sb_hy[m] = readlane_f(y1, 0);
+    }
+    __syncthreads();                                      // window intervals visible
     const long long t_sorted = np.stats ? (long long)__builtin_readcyclecounter() : 0ll;
 
     // ---- 2b / 3. all pairs (i before j), wave-local queue
@@ -887,7 +960,11 @@ __device__ inline bool nms_pairs_body(
                 yes = suppresses_nodiv(bi, ai, bk, thr, k_hi, k_lo, u_min);
             }
             const unsigned long long ym = __ballot(yes);
-            if (yes) q[ne + __builtin_amdgcn_mbcnt_hi((uint32_t)(ym >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ym, 0u))] = e;
+            if (yes) {      // a true edge leaves the spatial positions behind: (rank of the earlier box, rank of the later one)
+                const uint32_t ra = SPATIAL ? (uint32_t)s_rank[e >> 16] : (e >> 16), rb = SPATIAL ? (uint32_t)s_rank[e & 0xffffu] : (e & 0xffffu);
+                q[ne + __builtin_amdgcn_mbcnt_hi((uint32_t)(ym >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ym, 0u))] =
+                    ra < rb ? ((ra << 16) | rb) : ((rb << 16) | ra);
+            }
             ne += (uint32_t)__popcll(ym);
         }
         nq = ne;
@@ -904,14 +981,25 @@ __device__ inline bool nms_pairs_body(
         const bool intra = (m0 * W + ((m0 & 1) ? (W - 1 - wv) : wv)) == ic;
         const int c0 = ic << 6, cn = min(64, n - c0);
         for (int t0 = 0; t0 < cn && !ovf; t0 += 32) {
+            // slots (from m0 on) whose bounding intervals meet those of this window of 32 boxes: the others cannot pass the filter
+            int act = 0;
+            if (SPATIAL) {
+                const float4 wb4 = s_win[(ic << 1) + (t0 >> 5)];
+                const float w_lx = readlane_f(wb4.x, 0), w_ly = readlane_f(wb4.y, 0), w_hx = readlane_f(wb4.z, 0), w_hy = readlane_f(wb4.w, 0);
+#pragma unroll
+                for (int m = 0; m < JPT; ++m)
+                    if (m >= m0 && w_lx <= sb_hx[m] && sb_lx[m] <= w_hx && w_ly <= sb_hy[m] && sb_ly[m] <= w_hy) act |= 1 << m;
+                if (act == 0) continue;
+            } else act = ((1 << JPT) - 1) & ~((1 << m0) - 1);
             uint32_t hist[JPT];
 #pragma unroll
             for (int m = 0; m < JPT; ++m) hist[m] = 0u;
-            auto sweep = [&](auto first_slot) {
-                constexpr int M0 = decltype(first_slot)::value;
+            auto sweep = [&](auto slots) {
+                constexpr int MASK = decltype(slots)::value;
                 auto step = [&](const uint32_t rc, const uint32_t rr) {
 #pragma unroll
-                    for (int m = M0; m < JPT; ++m) {
+                    for (int m = 0; m < JPT; ++m) {
+                        if (!((MASK >> m) & 1)) continue;
                         const uint32_t d = __builtin_amdgcn_sad_u16(rc, cq[m], nj[m]);
                         // hist = 2 * hist + (d <= rr)
                         uint32_t hv = hist[m];
@@ -940,11 +1028,13 @@ __device__ inline bool nms_pairs_body(
                     step(nb.z, nb.w);
                 }
             };
-            switch (m0) {
-                case 0: sweep(std::integral_constant<int, 0>{}); break;
-                case 1: sweep(std::integral_constant<int, (JPT > 1 ? 1 : 0)>{}); break;
-                case 2: sweep(std::integral_constant<int, (JPT > 2 ? 2 : 0)>{}); break;
-                default: sweep(std::integral_constant<int, (JPT > 3 ? 3 : 0)>{}); break;
+            constexpr int ALL = (1 << JPT) - 1;
+            switch (act) {
+#define DETBOX_SWEEP(K) case K: sweep(std::integral_constant<int, (K) & ALL>{}); break;
+                DETBOX_SWEEP(1) DETBOX_SWEEP(2) DETBOX_SWEEP(3) DETBOX_SWEEP(4) DETBOX_SWEEP(5) DETBOX_SWEEP(6) DETBOX_SWEEP(7)
+                DETBOX_SWEEP(8) DETBOX_SWEEP(9) DETBOX_SWEEP(10) DETBOX_SWEEP(11) DETBOX_SWEEP(12) DETBOX_SWEEP(13) DETBOX_SWEEP(14)
+                default: sweep(std::integral_constant<int, ALL>{}); break;
+#undef DETBOX_SWEEP
             }
             // bit 31 - k of a history is box i = c0 + t0 + k.  Inside box i's own chunk only the later boxes count.
             if (intra) {
@@ -964,7 +1054,32 @@ __device__ inline bool nms_pairs_body(
             if (nq + total > (uint32_t)QCAP) {
                 drain();
                 ++n_drains;
-                if (ne + total > (uint32_t)QCAP) { ovf = true; break; }
+            }
+            if (ne + total > (uint32_t)QCAP) {
+                // A window of large boxes against a slot of large boxes can pass more pairs than the queue holds: it is
+                // appended one box i at a time (at most 64 * JPT pairs each), drained in between; only true edges can
+                // overflow the queue.
+                for (int k = 0; k < 32; ++k) {
+                    const uint32_t bitm = 0x80000000u >> k;                 // bit 31 - k: box c0 + t0 + k
+                    uint32_t ck = 0u;
+#pragma unroll
+                    for (int m = 0; m < JPT; ++m) ck += (hist[m] & bitm) ? 1u : 0u;
+                    if (__ballot(ck != 0u) == 0ull) continue;
+                    const uint32_t inck = wave_inclusive_add(ck);
+                    const uint32_t totk = (uint32_t)__builtin_amdgcn_readlane((int)inck, 63);
+                    if (nq + totk > (uint32_t)QCAP) {
+                        drain();
+                        ++n_drains;
+                        if (ne + totk > (uint32_t)QCAP) { ovf = true; break; }
+                    }
+                    uint32_t *qk = q + (nq + inck - ck);
+#pragma unroll
+                    for (int m = 0; m < JPT; ++m)
+                        if (hist[m] & bitm) *qk++ = ((uint32_t)(c0 + t0 + k) << 16) | (uint32_t)pos[m];
+                    nq += totk;
+                    n_passed += totk;
+                }
+                continue;
             }
             uint32_t *qp = q + (nq + inc - cnt);
 #pragma unroll
@@ -1081,7 +1196,7 @@ __device__ inline bool nms_pairs_body(
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < JPT; ++m) {
-        const int i = pos[m];
+        const int i = tid + m * BLK;
         if (i >= n) continue;
         const unsigned long long rem = s_removed[i >> 6];
         if ((rem >> (i & 63)) & 1ull) continue;
