@@ -719,6 +719,46 @@ def test_nms_pair_list_and_its_fall_back(D, oracle, dev):
         L.detbox_debug_nms_stats_enable(0)
 
 
+def test_nms_spatial_order_mixed_sizes(D, oracle, dev):
+    """The four-wave pair-list kernel orders a segment by size class and row before its all-pairs phase and skips whole
+    windows by bounding intervals.  Segments that mix the classes: long thin bars that pass the centre-distance filter
+    against each other by the thousand without suppressing anything (more passing pairs in one window than a wave's queue
+    holds: they are appended box by box, and nothing falls back), medium boxes, a crowd of small ones, boxes without
+    area, and the same with everything in one row."""
+    import ctypes
+    O = oracle
+    L = D.ops._lib.lib()
+    g = torch.Generator().manual_seed(2718)
+    out = (ctypes.c_uint64 * 8)()
+    k = torch.arange(64, dtype=torch.float32)
+    bars = torch.stack([0.1 + 0 * k, 0.1 + 0.0125 * k, 0.9 + 0 * k, 0.12 + 0.0125 * k], 1)      # IoU of neighbours 0.23
+    medium = rand_boxes(g, 100, spread=0.8, size=0.15)
+    small = rand_boxes(g, 830, spread=0.9, size=0.03)
+    flat = small.clone()
+    flat[:, 1] = 0.5
+    flat[:, 3] = 0.5 + 0.02 * torch.rand(830, generator=g)
+    L.detbox_debug_nms_stats_enable(1)
+    try:
+        for name, boxes in (('mixed', torch.cat([bars, medium, small])), ('one row', torch.cat([bars, medium, flat])),
+                            ('bars only', bars.repeat(4, 1) + 0.001 * torch.rand(256, 4, generator=g))):
+            n = boxes.shape[0]
+            boxes = boxes[torch.randperm(n, generator=g)]
+            boxes[5, 2] = boxes[5, 0]                                   # no width
+            boxes[9, 3] = boxes[9, 1] - 0.1                             # negative height
+            scores = torch.rand(n, generator=g)
+            idxs = torch.zeros(n, dtype=torch.long)
+            L.detbox_debug_nms_stats(out, 1)
+            got = D.batched_nms(boxes.to(dev), scores.to(dev), idxs.to(dev), 0.45)
+            L.detbox_debug_nms_stats(out, 1)
+            st = [int(x) for x in out]
+            assert torch.equal(got.cpu(), O.batched_nms(boxes, scores, idxs, 0.45)), name
+            assert st[0] == 1, (name, st)
+            if name == 'mixed':
+                assert st[1] == 0 and st[2] > 1500 and st[3] <= st[2], st      # no fall-back; the bars alone pass ~2000 pairs
+    finally:
+        L.detbox_debug_nms_stats_enable(0)
+
+
 def test_nms_thousands_of_short_segments(D, oracle, dev):
     """Launches with >= 4096 short segments take the one-wave-per-segment kernel: every register-slot
     count of it (segments up to 64, 128 and 256 boxes) against the oracle."""
