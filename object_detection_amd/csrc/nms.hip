@@ -688,10 +688,16 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == 256 
 // is a function of the set of edges {(i, j): i before j, iou(i, j) > thr} alone, so the kernel first finds
 // all edges -- an order-free all-pairs join with no dependency between pairs -- and only then walks them
 // in score order:
-//   1. sort (registers, as in the chunked kernel); every wave then owns JPT 64-box chunks of the sorted
-//      order, dealt boustrophedon so that the four waves (one per SIMD) carry equal shares of the triangle;
+//   1. sort (registers, as in the chunked kernel): every box learns its rank in score order.  The four-wave
+//      form then lays the boxes out in a *spatial* order for the join, by a counting sort in LDS: one bin for
+//      the large boxes (radius r below), then 256 rows of the centre for the medium and 256 for the small ones.
+//      Which of two boxes comes first in that order is irrelevant to the join (every unordered pair is met
+//      once); 32 consecutive boxes now share a narrow band of the image.  Every wave owns JPT 64-box chunks of
+//      the order, dealt boustrophedon so that the four waves (one per SIMD) carry equal shares of the triangle;
 //   2. filter: box i (broadcast from LDS) against a wave's 64-box slots with three VALU instructions per 64
-//      pairs.  With p = |cx_i - cx_j|, q = |cy_i - cy_j|, W = (w_i + w_j) / 2, H = (h_i + h_j) / 2, the overlaps
+//      pairs, window by window of 32 boxes i.  A window and a slot each carry the bounding intervals of their
+//      centres -+ radii; when those do not meet in x or in y no pair of the two can pass, and the window is
+//      skipped for that slot (one specialised sweep per set of active slots).  With p = |cx_i - cx_j|, q = |cy_i - cy_j|, W = (w_i + w_j) / 2, H = (h_i + h_j) / 2, the overlaps
 //      satisfy  overlap_x <= W - p,  overlap_y <= H - q,  and  iou > thr  means
 //          overlap_x * overlap_y > t * (A_i + A_j),  t = thr / (1 + thr).
 //      By AM-GM  (W - p) + (H - q) >= 2 sqrt((W - p)(H - q)) > 2 sqrt(t (A_i + A_j)) >= sqrt(2 t) (sqrt A_i + sqrt A_j),
@@ -701,8 +707,9 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == 256 
 //      of 32).  After each window the set bits (a few pairs per thousand) become entries of the wave's own queue
 //      in LDS: one prefix sum over the lanes' bit counts hands every lane its places, no atomics, no ballots;
 //   3. exact test: the wave drains its queue 64 pairs at a time with the reference's fp32 arithmetic
-//      (division-free where margins decide, the IEEE division in the sliver) on the copy of the sorted boxes
-//      in LDS, compacting the true edges in place at the front of the queue;
+//      (division-free where margins decide, the IEEE division in the sliver; the test is symmetric in the two
+//      boxes, bit for bit) on the copy of the boxes in LDS, compacting the true edges in place at the front of
+//      the queue as (rank of the higher score, rank of the lower score);
 //   4. resolve: a few rounds of  removed' = { j : some edge (i, j) with i not removed }  from the empty set,
 //      one pass over the edges each, until a round changes nothing; long chains of edges take the
 //      chunk-by-chunk form instead (edges from earlier chunks remove their targets if the source was kept,
@@ -721,9 +728,10 @@ __device__ unsigned long long g_pair_stats[8];
 
 struct NmsPairLds { size_t box, q, irec, removed, mask, misc, wprefix, rank, win, total; };
 
-// Entries per wave queue.  A queue that fills up is drained (tested pairs leave, true edges stay at its front); the
-// segment goes to the chunked algorithm once a wave holds more than PAIR_QCAP - 64 true edges.  With 1000-box segments
-// the whole layout stays under 32 KB, so that five workgroups share a CU.
+// Entries per wave queue.  A queue that fills up is drained (tested pairs leave, true edges stay at its front); a window
+// that passes more pairs than are free is appended one box i at a time (at most 64 * JPT pairs each); the segment goes to
+// the chunked algorithm once the true edges of a wave leave no room for that.  With 1000-box segments the whole layout is
+// 31.0 KB: five workgroups share a CU (at 32 KB to the byte only four were resident).
 constexpr int PAIR_QCAP = 256;
 // Spatial order of the all-pairs phase: boxes are binned by size class and by the row of their centre (a counting sort:
 // one bin for the large boxes, 256 rows each for the medium and the small ones), so that 32 consecutive boxes share a
