@@ -142,21 +142,18 @@ class Workload:
         c = m.candidates(self.outputs(), 0.01, self.top_k)      # activation fused into the selection pass
         if 'select' in extra:
             c = m.candidates(self.outputs(), 0.01, self.top_k)
-        keep, kc = ops.nms_candidates(c, 0.45)
-        if 'nms' in extra:
-            keep, kc = ops.nms_candidates(c, 0.45)
+        # per-class NMS + order step + result rows: one operator (the order step writes the rows itself)
         if world == 1:
-            rows_ids, rows_vals, row_off = ops.pack_detections(c.boxes, c.scores, c.class_ids, keep, kc, self.ids, self.hw)
-            if 'pack' in extra:
-                rows_ids, rows_vals, row_off = ops.pack_detections(c.boxes, c.scores, c.class_ids, keep, kc, self.ids, self.hw)
+            keep, kc, rows_ids, rows_vals, row_off = ops.nms_rows(c, 0.45, self.ids, self.hw)
+            if 'nms' in extra:
+                keep, kc, rows_ids, rows_vals, row_off = ops.nms_rows(c, 0.45, self.ids, self.hw)
         else:
             # the exchange step: this rank's detections as a compact message; the gather of the previous
             # batch's messages starts now, on a side stream, and overlaps this batch's kernels
             if self.exchange is None:
                 self.exchange = RowExchange(keep_results=False, root=self.exchange_root)
                 self.hdr_rows = ops.wire_header_rows(self.B)
-            rows_ids, rows_vals, row_off, wire = ops.pack_detections(c.boxes, c.scores, c.class_ids, keep, kc, self.ids,
-                                                                     self.hw, wire_images_cap=self.B)
+            keep, kc, rows_ids, rows_vals, row_off, wire = ops.nms_rows(c, 0.45, self.ids, self.hw, wire_images_cap=self.B)
             self.exchange.submit(wire, self.B, self.hdr_rows)
         return targets, c, kc, rows_ids, rows_vals, row_off
 
@@ -201,7 +198,8 @@ def measured_traffic(workload, regime, kernel):
 
 KERNELS = ['assign_anchor', 'assign_fixup', 'assign_fcos', 'select_sample', 'select_plan', 'select_scan',
            'select_bucket', 'select_check', 'select_fallback', 'select_materialize', 'score_hist', 'select_kth',
-           'select_refine', 'select_emit', 'select_finalize', 'select_direct_stats', 'select_direct', 'nms_segments', 'nms_scan', 'nms_merge', 'pack_detections']
+           'select_refine', 'select_emit', 'select_finalize', 'select_direct_stats', 'select_direct', 'nms_segments', 'nms_scan', 'nms_merge',
+           'nms_split', 'nms_tile', 'pack_detections']
 PRICED = ('select_scan', 'score_hist', 'select_emit', 'assign_anchor', 'assign_fcos', 'nms_segments', 'select_finalize',
           'select_direct_stats', 'select_direct')
 

@@ -218,6 +218,25 @@ int detbox_pack_detections(const float *boxes, const float *scores, const int64_
                            int64_t B, int64_t stride,
                            int64_t *rows_ids, double *rows_vals, int32_t *row_offsets, void *stream);
 
+/* detbox_batched_nms_segments and detbox_pack_detections (and, with wire != NULL, detbox_pack_wire) as one call:
+ * replaces src/utilities/predictor.py:52-73 for a batch -- batched_nms at :55, the gathers at :56-58 and the
+ * per-detection loop at :60-73.  The order step of the NMS writes the result rows itself, so the keep lists are
+ * not read back and the kept boxes are gathered once.
+ *   class_ids     [B*stride]; every row of a segment carries the same class id (a segment IS a class)
+ *   keep          [B*stride] (required), keep_counts [B]: as detbox_batched_nms_segments
+ *   rows_ids, rows_vals, row_offsets: as detbox_pack_detections; an image whose keep_counts is -1 gets no rows
+ *   images_cap, wire: as detbox_pack_wire, or wire == NULL for no message
+ * Workspace: detbox_nms_rows_workspace_bytes (equal to detbox_batched_nms_segments_workspace_bytes). */
+size_t detbox_nms_rows_workspace_bytes(int64_t B, int64_t stride, int64_t S);
+int detbox_nms_rows(const float *boxes, const float *scores, const int64_t *class_ids,
+                    const int32_t *seg_offsets, int64_t B, int64_t stride, int64_t S, int64_t max_segment,
+                    double iou_threshold, int presorted,
+                    const int64_t *image_ids, const int32_t *image_sizes,
+                    int64_t *keep, int32_t *keep_counts,
+                    int64_t *rows_ids, double *rows_vals, int32_t *row_offsets,
+                    int64_t images_cap, uint32_t *wire,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- multi-GPU exchange of detections ---------------------------------------------------- */
 
 /* Compact, self-describing message with one rank's kept detections, for the all-gather that precedes
@@ -251,7 +270,7 @@ int detbox_pack_detections_wire(const float *boxes, const float *scores, const i
  * "box_iou", "assign_anchor", "assign_fixup", "assign_fcos", "activate_scores", "select_sample",
  * "select_plan", "select_scan", "select_bucket", "select_check", "select_materialize", "score_hist", "select_kth",
  * "select_refine", "select_emit", "select_finalize", "select_direct_stats", "select_direct", "nms_segments", "nms_scan", "nms_merge",
- * "nms_write", "pack_detections", "pack_wire", "topk_mask", "focal_forward", "focal_backward",
+ * "nms_split", "nms_tile", "pack_detections", "pack_wire", "topk_mask", "focal_forward", "focal_backward",
  * "smooth_l1_forward", "smooth_l1_backward". */
 int detbox_profile_enable(int on);
 /* Restricts the timing to the one kernel called `name` (NULL or "" = every kernel again), so that a
@@ -272,7 +291,19 @@ int detbox_debug_stream_read(const float *in, int64_t n, float *out, int blocks,
  * [3] pairs with iou above the threshold, [4] queue drains; [5..7] clock cycles of each segment's first wave in the
  * three phases (sort and records; all pairs; resolve and output), summed over segments. */
 int detbox_debug_nms_stats_enable(int on);
+/* Measurement and test aid: on != 0 makes detbox_batched_nms_segments / detbox_nms_rows order the kept boxes with the
+ * level-by-level merge (and pack the rows in a pass of their own) for every shape, as they do for shapes the tile merge
+ * does not hold (more than 256 segments per image).  Also set by the environment variable DETBOX_NMS_LEVEL_MERGE at
+ * load time.  The workspace sizes follow the switch: query them again after changing it. */
+int detbox_debug_nms_level_merge(int on);
 int detbox_debug_nms_stats(uint64_t *out8, int reset);
+
+/* Measurement aid, not part of the box-ops path: counters of the order step (nms_split / nms_tile kernels), summed over
+ * all launches on the current device since the last reset while switched on (enable != 0 switches the collection on for
+ * the launches that follow, 0 off).  Synchronises the device.  out8[0] tile workgroups, [1] of them ordered by the
+ * merge-path levels instead of the distribution sort, [2..5] clock cycles of a tile workgroup's first wave in its four
+ * phases (set-up and piece bounds; piece loads; sort; output), [6] split workgroups that sampled, [7] their cycles. */
+int detbox_debug_merge_stats(uint64_t *out8, int enable, int reset);
 
 #ifdef __cplusplus
 }

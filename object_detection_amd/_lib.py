@@ -34,9 +34,14 @@ SIGNATURES = {
                                     _p, _p, _p, _p, _p, _p, _sz, _p]),
     'detbox_batched_nms_segments_workspace_bytes': (_sz, [_i64, _i64, _i64]),
     'detbox_batched_nms_segments': (_i32, [_p, _p, _p, _i64, _i64, _i64, _i64, _f64, _i32, _p, _p, _p, _sz, _p]),
+    'detbox_nms_rows_workspace_bytes': (_sz, [_i64, _i64, _i64]),
+    'detbox_nms_rows': (_i32, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _f64, _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _p,
+                               _p, _sz, _p]),
     'detbox_pack_detections': (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
     'detbox_debug_stream_read': (_i32, [_p, _i64, _p, _i32, _p]),
     'detbox_debug_nms_stats_enable': (_i32, [_i32]),
+    'detbox_debug_nms_level_merge': (_i32, [_i32]),
+    'detbox_debug_merge_stats': (_i32, [_p, _i32, _i32]),
     'detbox_debug_nms_stats': (_i32, [_p, _i32]),
     'detbox_wire_header_rows': (_i64, [_i64]),
     'detbox_pack_wire': (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p]),

@@ -34,7 +34,28 @@ struct Carver {
     }
 };
 
-#define DETBOX_CHECK_ARG(cond, msg)                                   \
+// ---- order step of the batched NMS + result rows (merge.hip), driven from nms.hip -----------------------------
+// How the kept runs of one image are cut into tiles: every SP-th run element is a sample, every Q-th merged sample a
+// splitter, at most T_max tiles per image.  ok == false: the shape is outside what the tile kernels hold
+// (more than 256 segments per image, or tiles that would not fit) and the caller takes the level-by-level merge.
+struct MergePlan { bool ok; int SP, Q, T_max; };
+MergePlan merge_plan(int64_t stride, int64_t S);
+size_t merge_workspace_bytes(const MergePlan &p, int64_t B, int64_t S);
+
+// Where the result rows go (all device pointers; wire may be null).
+struct RowsOut {
+    const float4 *boxes; const float *scores; const int64_t *class_ids;
+    const int64_t *image_ids; const int32_t *image_sizes;
+    int64_t *rows_ids; double *rows_vals; int32_t *row_offsets;
+    int hdr_rows; uint32_t *wire;
+};
+// kept: per (image, segment) run of (ordered score key, row) pairs starting at the segment's first row; kcount [B,S].
+// Writes keep_counts, keep (unless null) and, with rows != null, the result rows.
+int merge_rows_launch(const MergePlan &p, const float2 *kept, const int32_t *kcount, const int32_t *seg_offsets,
+                      int64_t B, int64_t stride, int64_t S, int64_t *keep, int32_t *keep_counts, const RowsOut *rows,
+                      void *workspace, hipStream_t st);
+
+#define DETBOX_CHECK_ARG(cond, msg)                                 \
     do { if (!(cond)) { detbox::set_error("%s: %s", __func__, msg);   \
                         return DETBOX_ERR_INVALID; } } while (0)
 

@@ -1592,15 +1592,27 @@ const bool g_nms_chunked_only = std::getenv("DETBOX_NMS_CHUNKED") != nullptr;
 // DETBOX_NMS_STATS=1: the pair-list kernel adds to the counters detbox_debug_nms_stats reads (a few atomics per wave)
 bool g_nms_stats = std::getenv("DETBOX_NMS_STATS") != nullptr;     // also switched by detbox_debug_nms_stats_enable
 
-struct NmsLayout { size_t kept_a, kept_b, kcount, koff, total; };
+struct NmsLayout { size_t kept_a, kept_b, kcount, koff, merge, total; };
 
+// DETBOX_NMS_LEVEL_MERGE=1 (measurements, tests): always the level-by-level merge, never the tile merge
+bool g_nms_level_merge = std::getenv("DETBOX_NMS_LEVEL_MERGE") != nullptr;     // also switched by detbox_debug_nms_level_merge
+
+MergePlan nms_merge_plan(int64_t stride, int64_t S) {
+    MergePlan p = merge_plan(stride, S);
+    if (g_nms_level_merge) p.ok = false;
+    return p;
+}
+
+// The tile merge reads the kept runs once and needs no second run buffer; the level-by-level merge ping-pongs.
 NmsLayout nms_layout(int64_t B, int64_t stride, int64_t S) {
     NmsLayout L;
+    const MergePlan p = nms_merge_plan(stride, S);
     size_t off = 0;
     L.kept_a = off; off = align_up(off + (size_t)B * stride * sizeof(float2), 256);
-    L.kept_b = off; off = align_up(off + (size_t)B * stride * sizeof(float2), 256);
+    L.kept_b = off; off = align_up(off + (p.ok ? 0 : (size_t)B * stride * sizeof(float2)), 256);
     L.kcount = off; off = align_up(off + (size_t)B * S * sizeof(int32_t), 256);
     L.koff = off; off = align_up(off + (size_t)B * (S + 1) * sizeof(int32_t), 256);
+    L.merge = off; off = align_up(off + (p.ok ? merge_workspace_bytes(p, B, S) : 0), 256);
     L.total = off;
     return L;
 }
@@ -1612,11 +1624,15 @@ extern "C" size_t detbox_batched_nms_segments_workspace_bytes(int64_t B, int64_t
     return nms_layout(B, stride, S).total;
 }
 
-extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scores, const int32_t *seg_offsets,
-                                           int64_t B, int64_t stride, int64_t S, int64_t max_segment,
-                                           double iou_threshold, int presorted,
-                                           int64_t *keep, int32_t *keep_counts,
-                                           void *workspace, size_t workspace_bytes, void *stream) {
+namespace {
+// NMS of every segment, then the order step.  rows == null: the keep lists only.  rows != null: the result rows as
+// well (keep may then be null); *rows_done tells the caller whether they were written here (tile merge) or are still
+// to be packed from the keep lists (level-by-level merge).
+int nms_run(const float *boxes, const float *scores, const int32_t *seg_offsets,
+            int64_t B, int64_t stride, int64_t S, int64_t max_segment, double iou_threshold, int presorted,
+            int64_t *keep, int32_t *keep_counts, const RowsOut *rows, bool *rows_done,
+            void *workspace, size_t workspace_bytes, void *stream) {
+    if (rows_done) *rows_done = false;
     DETBOX_CHECK_ARG(B >= 0 && stride >= 0 && S >= 0, "negative size");
     DETBOX_CHECK_ARG(!(iou_threshold != iou_threshold), "iou_threshold is NaN");
     DETBOX_CHECK_ARG(B <= 65535 && S <= (1 << 30) && stride < (1ll << 31), "size too large");
@@ -1627,7 +1643,7 @@ extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scor
         DETBOX_HIP(hipMemsetAsync(keep_counts, 0, (size_t)B * sizeof(int32_t), st));
         return DETBOX_OK;
     }
-    DETBOX_CHECK_ARG(boxes && scores && seg_offsets && keep, "null pointer");
+    DETBOX_CHECK_ARG(boxes && scores && seg_offsets && (keep || rows), "null pointer");
     DETBOX_CHECK_ARG((uintptr_t)boxes % 16 == 0, "boxes must be 16-byte aligned");
     if (max_segment <= 0 || max_segment > stride) max_segment = stride;
     if (!presorted && max_segment > DETBOX_NMS_MAX_SORT) max_segment = DETBOX_NMS_MAX_SORT;
@@ -1717,6 +1733,12 @@ extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scor
         }
         DETBOX_LAUNCH_CHECK();
     }
+    const MergePlan plan = nms_merge_plan(stride, S);
+    if (plan.ok) {
+        if (rows_done) *rows_done = rows != nullptr;
+        return merge_rows_launch(plan, kept_a, kcount, seg_offsets, B, stride, S, keep, keep_counts, rows, ws + L.merge, st);
+    }
+    DETBOX_CHECK_ARG(keep, "null pointer");
     long long F = 1;                       // as many merge levels as fit in LDS at once
     while (F * 2 * max_segment <= ML_CAP && F < 64 && F < S) F *= 2;
     const bool scan_in_merge = F > 1 && S <= ML_SCAN_MAX;
@@ -1754,6 +1776,22 @@ extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scor
         float2 *tmp = src; src = dst; dst = tmp;
         group *= 2;
     }
+    return DETBOX_OK;
+}
+}  // namespace
+
+extern "C" int detbox_batched_nms_segments(const float *boxes, const float *scores, const int32_t *seg_offsets,
+                                           int64_t B, int64_t stride, int64_t S, int64_t max_segment,
+                                           double iou_threshold, int presorted,
+                                           int64_t *keep, int32_t *keep_counts,
+                                           void *workspace, size_t workspace_bytes, void *stream) {
+    DETBOX_CHECK_ARG(keep || B == 0 || stride == 0 || S == 0, "null pointer");
+    return nms_run(boxes, scores, seg_offsets, B, stride, S, max_segment, iou_threshold, presorted, keep, keep_counts,
+                   nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int detbox_debug_nms_level_merge(int on) {
+    g_nms_level_merge = on != 0;
     return DETBOX_OK;
 }
 
@@ -1824,6 +1862,36 @@ extern "C" int detbox_pack_detections_wire(const float *boxes, const float *scor
                                            int64_t *rows_ids, double *rows_vals, int32_t *row_offsets,
                                            int64_t images_cap, uint32_t *wire, void *stream) {
     DETBOX_CHECK_ARG(wire, "null pointer");
+    return pack_rows(boxes, scores, class_ids, keep, keep_counts, image_ids, image_sizes, B, stride, rows_ids, rows_vals,
+                     row_offsets, images_cap, wire, stream);
+}
+
+extern "C" size_t detbox_nms_rows_workspace_bytes(int64_t B, int64_t stride, int64_t S) {
+    return detbox_batched_nms_segments_workspace_bytes(B, stride, S);
+}
+
+extern "C" int detbox_nms_rows(const float *boxes, const float *scores, const int64_t *class_ids,
+                               const int32_t *seg_offsets, int64_t B, int64_t stride, int64_t S, int64_t max_segment,
+                               double iou_threshold, int presorted,
+                               const int64_t *image_ids, const int32_t *image_sizes,
+                               int64_t *keep, int32_t *keep_counts,
+                               int64_t *rows_ids, double *rows_vals, int32_t *row_offsets,
+                               int64_t images_cap, uint32_t *wire,
+                               void *workspace, size_t workspace_bytes, void *stream) {
+    DETBOX_CHECK_ARG(B >= 0 && stride >= 0 && S >= 0, "negative size");
+    DETBOX_CHECK_ARG(row_offsets && keep_counts, "null pointer");
+    DETBOX_CHECK_ARG(!wire || images_cap >= B, "images_cap smaller than the number of images");
+    if (B > 0 && stride > 0)
+        DETBOX_CHECK_ARG(class_ids && image_ids && image_sizes && rows_ids && rows_vals && keep, "null pointer");
+    RowsOut ro;
+    ro.boxes = reinterpret_cast<const float4 *>(boxes); ro.scores = scores; ro.class_ids = class_ids;
+    ro.image_ids = image_ids; ro.image_sizes = image_sizes;
+    ro.rows_ids = rows_ids; ro.rows_vals = rows_vals; ro.row_offsets = row_offsets;
+    ro.hdr_rows = wire ? (int)detbox_wire_header_rows(images_cap) : 0; ro.wire = wire;
+    bool rows_done = false;
+    const int rc = nms_run(boxes, scores, seg_offsets, B, stride, S, max_segment, iou_threshold, presorted, keep, keep_counts,
+                           &ro, &rows_done, workspace, workspace_bytes, stream);
+    if (rc != DETBOX_OK || rows_done) return rc;
     return pack_rows(boxes, scores, class_ids, keep, keep_counts, image_ids, image_sizes, B, stride, rows_ids, rows_vals,
                      row_offsets, images_cap, wire, stream);
 }

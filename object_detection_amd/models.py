@@ -113,11 +113,10 @@ class _BoxOps:
         synchronisation too and returns (rows_ids, rows_vals, row_offsets) with the buffers at full length
         (rows beyond row_offsets[-1] unused) -- the form for batches in flight on several streams."""
         c = self.candidates(outputs, conf_thresh, top_k)
-        keep, kc = ops.nms_candidates(c, iou_thresh)
         dev = c.boxes.device
         ids = torch.tensor([m['image_id'] for m in image_metas], dtype=torch.int64).to(dev, non_blocking=True)
         hw = torch.tensor([[m['height'], m['width']] for m in image_metas], dtype=torch.int32).to(dev, non_blocking=True)
-        rows_ids, rows_vals, row_off = ops.pack_detections(c.boxes, c.scores, c.class_ids, keep, kc, ids, hw)
+        _, _, rows_ids, rows_vals, row_off = ops.nms_rows(c, iou_thresh, ids, hw)
         if not trim:
             return rows_ids, rows_vals, row_off
         n = int(row_off[-1].item())

@@ -5,7 +5,7 @@ imports (src/models/ssd300.py:5, src/utilities/predictor.py:3, src/datasets/data
     box_convert(boxes, in_fmt, out_fmt), box_iou(boxes1, boxes2),
     batched_nms(boxes, scores, idxs, iou_threshold)
 Level 1b -- the fused batch operators the model classes in models.py are built on:
-    assign_anchor, assign_fcos, select_decode, nms_candidates, pack_detections
+    assign_anchor, assign_fcos, select_decode, nms_candidates, pack_detections, nms_rows
 
 Every operator runs on the GPU through libdetbox.so.  CPU tensors are accepted for
 the Level-1 functions (they are copied to the current GPU and the result is copied
@@ -330,6 +330,53 @@ def nms_segments(boxes: torch.Tensor, scores: torch.Tensor, seg_offsets: torch.T
 
 def nms_candidates(c: Candidates, iou_threshold: float) -> Tuple[torch.Tensor, torch.Tensor]:
     return nms_segments(c.boxes, c.scores, c.seg_offsets, iou_threshold, max_segment=c.top_k, presorted=False)
+
+
+def nms_rows(c: Candidates, iou_threshold: float, image_ids: torch.Tensor, image_sizes: torch.Tensor,
+             wire_images_cap: Optional[int] = None, presorted: bool = False, max_segment: Optional[int] = None):
+    """nms_candidates + pack_detections as one operator (src/utilities/predictor.py:52-73 for a batch): the order step
+    of the NMS writes the result rows itself.
+    -> keep [B,stride] i64, keep_counts [B] i32, rows_ids [B*stride,2] i64, rows_vals [B*stride,5] f64,
+       row_offsets [B+1] i32 (, wire [header_rows + B*stride, 6] i32 with wire_images_cap)."""
+    dev = c.boxes.device
+    boxes, scores, cls = _dense(c.boxes), _dense(c.scores), _dense(c.class_ids, torch.int64)
+    seg = _dense(c.seg_offsets, torch.int32)
+    image_sizes = _dense(_to(image_sizes, dev), torch.int32)
+    image_ids = _dense(_to(image_ids, dev), torch.int64)
+    B, stride = scores.shape
+    S = seg.shape[1] - 1
+    if boxes.shape != (B, stride, 4) or cls.shape != (B, stride) or seg.shape[0] != B or image_ids.numel() != B \
+            or image_sizes.shape != (B, 2):
+        raise ValueError('nms_rows: shapes do not fit')
+    if wire_images_cap is not None and B > wire_images_cap:
+        raise ValueError('nms_rows: more images than wire_images_cap')
+    keep = torch.empty((B, stride), dtype=torch.int64, device=dev)
+    kc = torch.empty((B,), dtype=torch.int32, device=dev)
+    rows_ids = torch.empty((B * stride, 2), dtype=torch.int64, device=dev)
+    rows_vals = torch.empty((B * stride, 5), dtype=torch.float64, device=dev)
+    row_off = torch.empty((B + 1,), dtype=torch.int32, device=dev)
+    wire = None
+    if wire_images_cap is not None:
+        wire = torch.empty((wire_header_rows(wire_images_cap) + B * stride, 6), dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    with _on(dev):
+        st = _stream(dev)
+        ws = _workspace(dev, _ws_bytes(L.detbox_nms_rows_workspace_bytes, B, stride, S), 'nms', st)
+        _lib.check(L.detbox_nms_rows(_ptr(boxes), _ptr(scores), _ptr(cls), _ptr(seg), B, stride, S,
+                                     int(c.top_k if max_segment is None else max_segment), float(iou_threshold), int(presorted),
+                                     image_ids.data_ptr(), image_sizes.data_ptr(), _ptr(keep), kc.data_ptr(),
+                                     _ptr(rows_ids), _ptr(rows_vals), row_off.data_ptr(),
+                                     int(wire_images_cap or 0), None if wire is None else wire.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), st), 'detbox_nms_rows')
+    if wire is None:
+        return keep, kc, rows_ids, rows_vals, row_off
+    return keep, kc, rows_ids, rows_vals, row_off, wire
+
+
+def nms_level_merge(on: bool):
+    """Test / measurement switch: order the kept boxes with the level-by-level merge for every shape."""
+    _lib.check(_lib.lib().detbox_debug_nms_level_merge(int(on)), 'detbox_debug_nms_level_merge')
+    _ws_sizes.clear()
 
 
 def pack_detections(boxes, scores, class_ids, keep, keep_counts, image_ids: torch.Tensor, image_sizes: torch.Tensor,

@@ -4,8 +4,9 @@ result format) with the NMS and the row arithmetic on the GPU.
 
 `run` accepts what the reference's `run` accepts (lists of per-image boxes / scores /
 class ids, on any device).  When every image's class ids are non-decreasing -- which is
-how every pre_predict emits them -- the whole batch goes through one segmented-NMS call
-and one packing call; otherwise each image goes through the generic batched_nms.
+how every pre_predict emits them -- the whole batch goes through one call that does the
+segmented NMS and writes the result rows; otherwise each image goes through the generic
+batched_nms and one packing call follows.
 """
 from __future__ import annotations
 
@@ -90,10 +91,9 @@ class Predictor:
         if c is not None and c.boxes.shape[0] == B:
             dev = c.boxes.device
             with torch.cuda.device(dev):
-                keep, kc = ops.nms_candidates(c, self.iou_thresh)
                 ids = torch.tensor([m['image_id'] for m in image_metas], dtype=torch.int64).to(dev, non_blocking=True)
                 hw = torch.tensor([[m['height'], m['width']] for m in image_metas], dtype=torch.int32).to(dev, non_blocking=True)
-                rows_ids, rows_vals, row_off = ops.pack_detections(c.boxes, c.scores, c.class_ids, keep, kc, ids, hw)
+                keep, kc, rows_ids, rows_vals, row_off = ops.nms_rows(c, self.iou_thresh, ids, hw)
                 n = int(row_off[-1].item())
                 if bool((kc < 0).any().item()):
                     raise DetboxError('NMS reported an over-long segment')
@@ -127,8 +127,8 @@ class Predictor:
             if fast:
                 seg = torch.zeros((B, S + 1), dtype=torch.int32, device=dev)
                 seg[:, 1:] = torch.cumsum(onehot_counts, 1).to(torch.int32)
-                keep, kc = ops.nms_segments(boxes, scores, seg, self.iou_thresh,
-                                            max_segment=min(n_max, ops.NMS_MAX_SORT), presorted=False)
+                cand = ops.Candidates(boxes, scores, cls, seg, seg[:, -1].contiguous(), min(n_max, ops.NMS_MAX_SORT))
+                keep, kc, rows_ids, rows_vals, row_off = ops.nms_rows(cand, self.iou_thresh, ids, hw)
             else:
                 keep = torch.zeros((B, n_max), dtype=torch.int64, device=dev)
                 kcl = []
@@ -138,7 +138,7 @@ class Predictor:
                     keep[b, :k.numel()] = k
                     kcl.append(k.numel())
                 kc = torch.tensor(kcl, dtype=torch.int32, device=dev)
-            rows_ids, rows_vals, row_off = ops.pack_detections(boxes, scores, cls, keep, kc, ids, hw)
+                rows_ids, rows_vals, row_off = ops.pack_detections(boxes, scores, cls, keep, kc, ids, hw)
             offs = row_off.tolist()
             if any(o < 0 for o in offs) or bool((kc < 0).any().item()):
                 raise DetboxError('NMS reported an over-long segment')

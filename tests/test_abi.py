@@ -35,7 +35,10 @@ def test_library_exports_every_declared_symbol():
     assert L.detbox_box_convert(None, None, -1, 0, 0, None) == -1
     assert b'negative' in L.detbox_last_error()
     assert L.detbox_select_decode_workspace_bytes(16, 120087, 81, 1, 1000, 1) > 16 * 80 * 1000 * 8
-    assert L.detbox_batched_nms_segments_workspace_bytes(2, 4000, 20) >= 2 * 2 * 4000 * 8
+    # one buffer of kept runs (the tile merge reads it once); shapes beyond the tile merge keep the second one
+    assert 2 * 4000 * 8 <= L.detbox_batched_nms_segments_workspace_bytes(2, 4000, 20) < 2 * 2 * 4000 * 8
+    assert L.detbox_batched_nms_segments_workspace_bytes(2, 40000, 1000) >= 2 * 2 * 40000 * 8
+    assert L.detbox_nms_rows_workspace_bytes(2, 4000, 20) == L.detbox_batched_nms_segments_workspace_bytes(2, 4000, 20)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -775,6 +775,85 @@ def test_nms_thousands_of_short_segments(D, oracle, dev):
         assert torch.equal(got.cpu(), want), (ncls, per)
 
 
+def synth_candidates(D, dev, g, B, S, top_k, fill, size=0.02, tie_levels=0):
+    """Class-segmented candidates as select_decode emits them: segment s of image b holds fill(b, s) <= top_k rows."""
+    stride = S * top_k
+    boxes = torch.zeros(B, stride, 4)
+    scores = torch.zeros(B, stride)
+    cls = torch.zeros(B, stride, dtype=torch.int64)
+    seg = torch.zeros(B, S + 1, dtype=torch.int32)
+    for b in range(B):
+        o = 0
+        for s_ in range(S):
+            n = int(fill(b, s_))
+            boxes[b, o:o + n] = rand_boxes(g, n, spread=1.0, size=size)
+            sc = 0.01 + 0.98 * torch.rand(n, generator=g)
+            if tie_levels:
+                sc = (sc * tie_levels).round() / tie_levels + 0.01
+            scores[b, o:o + n] = sc
+            cls[b, o:o + n] = s_ + 1
+            o += n
+            seg[b, s_ + 1] = o
+    counts = seg[:, -1].clone()
+    return D.ops.Candidates(boxes.to(dev), scores.to(dev), cls.to(dev), seg.to(dev), counts.to(dev), top_k)
+
+
+def test_nms_rows_equals_nms_then_pack(D, oracle, dev):
+    """detbox_nms_rows (the order step cut into tiles that write the result rows themselves) against the two-step
+    path it replaces -- detbox_batched_nms_segments with the level-by-level merge, then detbox_pack_detections /
+    detbox_pack_wire -- bit for bit: keep lists, counts, rows, row offsets and the exchange message; and the keep
+    lists against the oracle's batched_nms.  Shapes: one tile per image, many tiles per image (more kept rows than a
+    workgroup holds, with score ties across classes and inside them), images without detections, one dominant class,
+    a single segment, the largest segment count."""
+    from object_detection_amd.dist import unpack_wire
+    O = oracle
+    g = torch.Generator().manual_seed(1234)
+    shapes = [
+        ('ssd-like', 3, 20, 200, lambda b, s: [200, 0, 37][b] if s % 3 else [200, 0, 1][b], 0.02, 0),
+        ('many tiles', 2, 80, 1000, lambda b, s: 1000 if b == 0 else (s * 13) % 1000, 0.004, 0),
+        ('many tiles, ties', 2, 80, 1000, lambda b, s: 900 + s, 0.004, 64),
+        ('one dominant class', 2, 40, 1000, lambda b, s: 1000 if s == 7 else 60, 0.004, 16),
+        ('single segment', 2, 1, 4096, lambda b, s: 4096 if b else 5, 0.002, 0),
+        ('256 segments', 1, 256, 64, lambda b, s: (s * 7) % 65, 0.01, 32),
+        ('all equal scores', 1, 80, 1000, lambda b, s: 700, 0.003, 1),
+    ]
+    for name, B, S, top_k, fill, size, ties in shapes:
+        c = synth_candidates(D, dev, g, B, S, top_k, fill, size, ties)
+        ids = torch.arange(100, 100 + B, dtype=torch.int64, device=dev)
+        ids[-1] = (1 << 41) + 5
+        hw = torch.tensor([[480 + 7 * b, 640 - 3 * b] for b in range(B)], dtype=torch.int32, device=dev)
+        D.ops.nms_level_merge(True)
+        try:
+            keep0, kc0 = D.ops.nms_candidates(c, 0.45)
+            rid0, rv0, ro0, wire0 = D.ops.pack_detections(c.boxes, c.scores, c.class_ids, keep0, kc0, ids, hw, wire_images_cap=B + 2)
+        finally:
+            D.ops.nms_level_merge(False)
+        keep1, kc1 = D.ops.nms_candidates(c, 0.45)
+        keep2, kc2, rid2, rv2, ro2, wire2 = D.ops.nms_rows(c, 0.45, ids, hw, wire_images_cap=B + 2)
+        keep3, kc3, rid3, rv3, ro3 = D.ops.nms_rows(c, 0.45, ids, hw)
+        torch.cuda.synchronize()
+        assert torch.equal(kc1, kc0) and torch.equal(kc2, kc0) and torch.equal(kc3, kc0), name
+        n = int(ro0[-1])
+        assert n == int(kc0.sum()) and torch.equal(ro2, ro0) and torch.equal(ro3, ro0), name
+        for b in range(B):
+            k = int(kc0[b])
+            assert torch.equal(keep1[b, :k], keep0[b, :k]) and torch.equal(keep2[b, :k], keep0[b, :k]), (name, b)
+            assert torch.equal(keep3[b, :k], keep0[b, :k]), (name, b)
+        assert torch.equal(rid2[:n], rid0[:n]) and torch.equal(rv2[:n], rv0[:n]), name
+        assert torch.equal(rid3[:n], rid0[:n]) and torch.equal(rv3[:n], rv0[:n]), name
+        hdr = D.ops.wire_header_rows(B + 2)
+        assert torch.equal(wire2[:hdr].reshape(-1)[:2 + 5 * B + 1], wire0[:hdr].reshape(-1)[:2 + 5 * B + 1]), name
+        assert torch.equal(wire2[hdr:hdr + n], wire0[hdr:hdr + n]), name
+        gid, gv = unpack_wire(wire2, hdr)
+        assert torch.equal(gid, rid0[:n]) and torch.equal(gv, rv0[:n]), name
+        if name in ('many tiles', 'many tiles, ties'):
+            assert int(kc0.max()) > 3 * 4096, (name, kc0.tolist())          # the tile merge really had several tiles
+        b = B - 1
+        cnt = int(c.counts[b])
+        want = O.batched_nms(c.boxes[b, :cnt].cpu(), c.scores[b, :cnt].cpu(), c.class_ids[b, :cnt].cpu(), 0.45)
+        assert torch.equal(keep2[b, :int(kc2[b])].cpu(), want), name
+
+
 def test_predictor_run_generic_inputs(D, oracle, dev):
     """Ungrouped class ids take the per-image path; grouped ones the batched path; same dicts."""
     O = oracle

@@ -3,7 +3,7 @@
 set -e
 mkdir -p gpurun_out
 ARGS="$@"      # e.g. --regime trained --steps 50
-for st in none assign select nms pack; do
+for st in none assign select nms; do
   DETBOX_BENCH_TWICE=$st timeout -k 10 150 python bench.py --no-extra --no-cpu-baseline $ARGS > gpurun_out/twice_$st.json 2> gpurun_out/twice_$st.err
   python - <<PY
 import json
