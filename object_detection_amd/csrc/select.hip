@@ -12,9 +12,9 @@
 //                   least top_k scores lie at or above it (or "stage all");
 //   select_scan     the one full pass: 64 anchors x C logits go HBM -> LDS by 16-byte LDS-DMA,
 //                   double buffered; four lanes share an anchor row for the soft-max; every
-//                   score >= t_lo is appended to the wave's own list (no atomics);
-//   select_bucket   counting sort of a scan workgroup's lists by class, one global atomic per
-//                   (workgroup, class) into that pair's staging list;
+//                   score >= t_lo is appended to the wave's own LDS list (no atomics), and a full
+//                   list goes to the per-(image,class) staging lists with one global atomic per
+//                   class present;
 //   select_check    verifies the guess (enough staged, not too many); pairs that fail are
 //                   handed to the exact two-pass fallback below and a flag is raised;
 //   select_finalize per (image,class): exact top_k of the staged keys by radix select,
@@ -66,7 +66,7 @@ struct SelRule {
 struct SelParams {
     int P, C, cb, Cs, top_k, cap, shift, tile_anchors;
     int use_sample, sample_rate, sample_m, subs_per_block, n_sub, tile_floats;
-    int ns_cap, blk_cap, scan_gx;
+    int ns_cap, scan_gx;
     long long total_floats;
     float thr;
     uint32_t key_thr;
@@ -557,27 +557,64 @@ template <int ACT, int EPT>
 __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__restrict__ in,
                                                                  const float *__restrict__ extra, SelParams sp,
                                                                  const SelRule *__restrict__ rules,
-                                                                 uint32_t *__restrict__ blk_cnt,
-                                                                 unsigned long long *__restrict__ blk_list,
-                                                                 uint32_t *__restrict__ img_ovf) {
+                                                                 uint32_t *__restrict__ gcnt,
+                                                                 unsigned long long *__restrict__ staging) {
     extern __shared__ float s_dynf[];
-    const int b = blockIdx.y, tid = threadIdx.x;
+    __shared__ uint32_t s_wc[SCAN_WAVES][MAX_SEL_CLASSES];     // per wave: entries per class of the list being flushed, then their bases
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int Cs = sp.Cs, cb = sp.cb, C = sp.C;
     const uint32_t key_thr = sp.key_thr;
     const SelRule *rb = rules + (size_t)b * Cs;
-    const size_t blk = (size_t)b * gridDim.x + blockIdx.x;
-    // every wave appends to its own quarter of the workgroup's list: no atomics, a wave-uniform count
+    // Every wave collects its candidates in an LDS list of its own (no atomics, a wave-uniform count) and hands full lists
+    // straight to the per-(image, class) staging lists: the entries of a list are counted per class in LDS, one global
+    // atomic per class present reserves their places, and the entries are scattered there.  The hand-over is split over
+    // two sub-tiles -- the atomics are issued behind one barrier, their results used behind the next, which waits for
+    // the sub-tile's DMA anyway -- and the wave fills its second list meanwhile, so nothing ever waits for an atomic.
     const int wv = tid >> 6;
-    const uint32_t wcap = (uint32_t)sp.blk_cap / SCAN_WAVES;
-    unsigned long long *wlist = blk_list + blk * sp.blk_cap + (size_t)wv * wcap;
-    uint32_t wn = 0, ln = 0;                              // entries flushed to the list; entries waiting in the LDS buffer
-    unsigned long long *ebuf = reinterpret_cast<unsigned long long *>(s_dynf + 2 * (size_t)sp.tile_floats + 4) + (size_t)wv * SCAN_EBUF;
-    auto flush = [&]() {
-        for (uint32_t k = (uint32_t)(tid & 63); k < ln; k += 64u)
-            if (wn + k < wcap) wlist[wn + k] = ebuf[k];
-        wn += ln;
+    uint32_t *wc = s_wc[wv];
+    unsigned long long *ebuf0 = reinterpret_cast<unsigned long long *>(s_dynf + 2 * (size_t)sp.tile_floats + 4) + (size_t)wv * 2 * SCAN_EBUF;
+    unsigned long long *ebuf = ebuf0, *pbuf = ebuf0 + SCAN_EBUF;
+    unsigned long long *stg = staging + (size_t)b * Cs * sp.cap;
+    uint32_t *gc = gcnt + (size_t)b * Cs;
+    const uint32_t cap = (uint32_t)sp.cap;
+    uint32_t ln = 0, pn = 0;                              // entries waiting in the current list; entries of the list being handed over
+    uint32_t pmeta[SCAN_EBUF / 64], gbase0 = 0, gbase1 = 0;
+    auto flush_begin = [&]() {                            // pn == 0
+        wc[lane] = 0u; wc[lane + 64] = 0u;
+#pragma unroll
+        for (int j = 0; j < SCAN_EBUF / 64; ++j) {
+            const uint32_t k = (uint32_t)lane + 64u * j;
+            pmeta[j] = 0u;
+            if (k < ln) {
+                const uint32_t ci = (uint32_t)(ebuf[k] >> 24) & 0xffu;
+                pmeta[j] = (ci << 16) | atomicAdd(&wc[ci], 1u);           // place among the list's entries of that class
+            }
+        }
+        const uint32_t c0 = wc[lane], c1 = wc[lane + 64];
+        gbase0 = c0 ? atomicAdd(&gc[lane], c0) : 0u;                      // c0 != 0 only for lane < Cs
+        gbase1 = c1 ? atomicAdd(&gc[lane + 64], c1) : 0u;
+        unsigned long long *t = ebuf; ebuf = pbuf; pbuf = t;
+        pn = ln;
         ln = 0u;
     };
+    auto flush_end = [&]() {
+        if (pn == 0u) return;
+        wc[lane] = gbase0; wc[lane + 64] = gbase1;
+#pragma unroll
+        for (int j = 0; j < SCAN_EBUF / 64; ++j) {
+            const uint32_t k = (uint32_t)lane + 64u * j;
+            if (k < pn) {
+                const unsigned long long en = pbuf[k];
+                const uint32_t ci = pmeta[j] >> 16;
+                const uint32_t pos = wc[ci] + (pmeta[j] & 0xffffu);
+                const uint32_t p = (uint32_t)en & 0xffffffu;
+                // a list that overflows keeps counting: select_check sees the count and hands the pair to the exact path
+                if (pos < cap) stg[(size_t)ci * cap + pos] = (en & 0xffffffff00000000ull) | (unsigned long long)(0xffffffffu - p);
+            }
+        }
+        pn = 0u;
+    };
+    auto flush = [&]() { flush_end(); flush_begin(); flush_end(); };       // inside a sub-tile: waits for its own atomics
     // the lane's classes never change: their staging thresholds live in registers (fetched into LDS by the first Cs
     // threads while the first sub-tile's DMA is in flight, then picked up by every lane)
     const int r = tid / LPR, sub = tid % LPR;
@@ -660,62 +697,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
                 }
             }
         },
-        // behind the barrier: the stores have the whole next sub-tile to complete before a barrier waits for them
-        [&](long long) { if (ln >= (uint32_t)SCAN_EBUF / 2u) flush(); }, fetch_thresholds, load_thresholds);
+        // behind the barrier: the atomics and the stores have the whole next sub-tile to complete before a barrier waits for them
+        [&](long long) {
+            flush_end();
+            if (ln >= (uint32_t)SCAN_EBUF / 2u) flush_begin();
+        }, fetch_thresholds, load_thresholds);
     flush();
-    if ((tid & 63) == 0) {
-        blk_cnt[blk * SCAN_WAVES + wv] = wn < wcap ? wn : wcap;
-        if (wn > wcap) img_ovf[b] = 1u;                   // the image falls back to the exact path
-    }
-}
-
-// Distributes one scan workgroup's candidate list over the per-(image,class) staging lists: counting
-// sort by class in LDS, one global atomic per class present, then the scatter.
-__global__ __launch_bounds__(256) void select_bucket_kernel(SelParams sp, const uint32_t *__restrict__ blk_cnt,
-                                                            const unsigned long long *__restrict__ blk_list,
-                                                            uint32_t *__restrict__ gcnt,
-                                                            unsigned long long *__restrict__ staging) {
-    __shared__ uint32_t s_ccount[MAX_SEL_CLASSES], s_cbase[MAX_SEL_CLASSES];
-    const int b = blockIdx.y, tid = threadIdx.x;
-    const size_t blk = (size_t)b * gridDim.x + blockIdx.x;
-    const int wcap = sp.blk_cap / SCAN_WAVES;
-    int nw[SCAN_WAVES];
-#pragma unroll
-    for (int w = 0; w < SCAN_WAVES; ++w) nw[w] = (int)blk_cnt[blk * SCAN_WAVES + w];
-    int nw_all = 0;
-#pragma unroll
-    for (int w = 0; w < SCAN_WAVES; ++w) nw_all += nw[w];
-    if (nw_all == 0) return;
-    const unsigned long long *list = blk_list + blk * sp.blk_cap;
-    const int Cs = sp.Cs, cap = sp.cap;
-    if (tid < MAX_SEL_CLASSES) s_ccount[tid] = 0u;
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < SCAN_WAVES; ++w)
-        for (int e = tid; e < nw[w]; e += 256) {
-            const uint32_t ci = (uint32_t)(list[w * wcap + e] >> 24) & 0xffu;
-            if (ci < (uint32_t)Cs) atomicAdd(&s_ccount[ci], 1u);          // entries are the scan's own; the check costs nothing
-        }
-    __syncthreads();
-    if (tid < Cs) {
-        const uint32_t c = s_ccount[tid];
-        s_cbase[tid] = c ? atomicAdd(&gcnt[(size_t)b * Cs + tid], c) : 0u;
-        s_ccount[tid] = 0u;
-    }
-    __syncthreads();
-    unsigned long long *stg = staging + (size_t)b * Cs * cap;
-#pragma unroll
-    for (int w = 0; w < SCAN_WAVES; ++w) {
-        for (int e = tid; e < nw[w]; e += 256) {
-            const unsigned long long en = list[w * wcap + e];
-            const uint32_t ci = (uint32_t)(en >> 24) & 0xffu;
-            if (ci >= (uint32_t)Cs) continue;
-            const uint32_t pos = s_cbase[ci] + atomicAdd(&s_ccount[ci], 1u);
-            const uint32_t p = (uint32_t)en & 0xffffffu;
-            if (pos < (uint32_t)cap)
-                stg[(size_t)ci * cap + pos] = (en & 0xffffffff00000000ull) | (unsigned long long)(0xffffffffu - p);
-        }
-    }
 }
 
 __global__ __launch_bounds__(128) void select_check_kernel(SelParams sp, SelRule *__restrict__ rules,
@@ -1430,7 +1417,6 @@ struct SelPlan {
     int use_sample, rate, m, cap;   // cap: entries of one (image,class) staging list
     int n_sub, ns_cap;              // sub-tiles per image; sampled rows per (image,class) (multiple of SUB_ROWS)
     int subs_per_block, scan_gx;    // scan: sub-tiles per workgroup, workgroups per image
-    int blk_cap;                    // entries of one scan workgroup's candidate list
 };
 
 // With a 1-in-rate sample, the score whose sample rank is m has, with probability about 1 - 3e-6
@@ -1458,7 +1444,7 @@ int64_t scan_resident_workgroups(int64_t C) {
         cus[dev] = n;
     }
     const size_t tile = (size_t)tile_floats_for(C) * 4;
-    const size_t lds = 2 * tile + 16 + (size_t)(SCAN_BLOCK / 64) * SCAN_EBUF * 8;
+    const size_t lds = 2 * tile + 16 + (size_t)(SCAN_BLOCK / 64) * 2 * SCAN_EBUF * 8 + sizeof(uint32_t) * SCAN_WAVES * MAX_SEL_CLASSES;
     int64_t per_cu = (int64_t)((160 * 1024) / lds);
     const int64_t want = per_cu_env ? per_cu_env : (int64_t)((40 * 1024 + tile - 1) / tile);
     if (per_cu > want) per_cu = want;
@@ -1493,7 +1479,7 @@ SelPlan make_plan(int64_t B, int64_t P, int64_t C, int64_t Cs, int top_k) {
         int slack = top_k / 2 > 256 ? top_k / 2 : 256;
         sp.use_sample = 0; sp.rate = 1; sp.m = 0; sp.cap = pow2_ge(top_k + slack);
         if (sp.cap < 512) sp.cap = 512;
-        sp.ns_cap = SUB_ROWS; sp.blk_cap = 256;
+        sp.ns_cap = SUB_ROWS;
         return sp;
     }
     static const int rate_big = [] { const char *e = std::getenv("DETBOX_SAMPLE_RATE"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 32; }();
@@ -1523,13 +1509,10 @@ SelPlan make_plan(int64_t B, int64_t P, int64_t C, int64_t Cs, int top_k) {
         rate /= 2;
     }
     sp.ns_cap = ((sp.n_sub + sp.rate - 1) / sp.rate) * SUB_ROWS;
-    // a scan workgroup sees subs_per_block*64 of the P anchors: twice its share of the worst case, plus slack
-    const double share = (double)sp.subs_per_block * SUB_ROWS / (double)P;
-    sp.blk_cap = pow2_ge((long long)(2.0 * share * upper * (double)Cs) + 1024);
     return sp;
 }
 
-struct SelLayout { size_t hist, cnt, flag, img_ovf, blk_cnt, rules, staging, samp, blk_list, scores, total; };
+struct SelLayout { size_t hist, cnt, flag, img_ovf, rules, staging, samp, scores, total; };
 
 bool use_direct(int64_t B, int64_t P, int64_t C) { return P <= DIRECT_MAX_P && B * P * C <= DIRECT_MAX_SCORES; }
 
@@ -1550,11 +1533,9 @@ SelLayout layout(int64_t B, int64_t P, int64_t C, int64_t Cs, const SelPlan &pl,
     L.cnt = off; off = align_up(off + (size_t)B * Cs * sizeof(uint32_t), 256);
     L.flag = off; off = align_up(off + sizeof(uint32_t), 256);
     L.img_ovf = off; off = align_up(off + (size_t)B * sizeof(uint32_t), 256);
-    L.blk_cnt = off; off = align_up(off + (size_t)B * pl.scan_gx * SCAN_WAVES * sizeof(uint32_t), 256);
     L.rules = off; off = align_up(off + (size_t)B * Cs * sizeof(SelRule), 256);
     L.staging = off; off = align_up(off + (size_t)B * Cs * pl.cap * sizeof(unsigned long long), 256);
     L.samp = off; off = align_up(off + (size_t)B * Cs * pl.ns_cap * sizeof(float), 256);
-    L.blk_list = off; off = align_up(off + (size_t)B * pl.scan_gx * pl.blk_cap * sizeof(unsigned long long), 256);
     L.scores = off;
     if (act != ACT_NONE) off = align_up(off + (size_t)B * P * C * sizeof(float), 256);   // fallback only
     L.total = off;
@@ -1572,9 +1553,9 @@ struct FastArgs {
     const float *in, *extra;
     SelParams sp;
     int64_t B;
-    uint32_t *flag, *cnt, *img_ovf, *blk_cnt, *hist;
+    uint32_t *flag, *cnt, *img_ovf, *hist;
     SelRule *rules;
-    unsigned long long *staging, *blk_list;
+    unsigned long long *staging;
     float *samp, *scores_ws;
     hipStream_t s;
 };
@@ -1608,17 +1589,12 @@ struct LaunchFast {
         }
         const unsigned gx = (unsigned)sp.scan_gx;
         if (sp.use_sample) {
-            const size_t lds = 2 * tile_bytes + 16 + (size_t)(SCAN_BLOCK / 64) * SCAN_EBUF * 8;
+            const size_t lds = 2 * tile_bytes + 16 + (size_t)(SCAN_BLOCK / 64) * 2 * SCAN_EBUF * 8;
             if (int rc = set_lds(select_scan_kernel<ACT, EPT>, lds)) return rc;
             {
                 ProfScope ps("select_scan", s);
                 select_scan_kernel<ACT, EPT><<<dim3(gx, (unsigned)a.B), dim3(SCAN_BLOCK), lds, s>>>(
-                    a.in, a.extra, sp, a.rules, a.blk_cnt, a.blk_list, a.img_ovf);
-                DETBOX_LAUNCH_CHECK();
-            }
-            {
-                ProfScope ps("select_bucket", s);
-                select_bucket_kernel<<<dim3(gx, (unsigned)a.B), dim3(256), 0, s>>>(sp, a.blk_cnt, a.blk_list, a.cnt, a.staging);
+                    a.in, a.extra, sp, a.rules, a.cnt, a.staging);
                 DETBOX_LAUNCH_CHECK();
             }
             ProfScope ps("select_check", s);
@@ -1784,11 +1760,9 @@ extern "C" int detbox_select_decode(int decode_mode, int activation, const float
     uint32_t *cnt = reinterpret_cast<uint32_t *>(ws + L.cnt);
     uint32_t *flag = reinterpret_cast<uint32_t *>(ws + L.flag);
     uint32_t *img_ovf = reinterpret_cast<uint32_t *>(ws + L.img_ovf);
-    uint32_t *blk_cnt = reinterpret_cast<uint32_t *>(ws + L.blk_cnt);
     SelRule *rules = reinterpret_cast<SelRule *>(ws + L.rules);
     unsigned long long *staging = reinterpret_cast<unsigned long long *>(ws + L.staging);
     float *samp = reinterpret_cast<float *>(ws + L.samp);
-    unsigned long long *blk_list = reinterpret_cast<unsigned long long *>(ws + L.blk_list);
     float *scores_ws = reinterpret_cast<float *>(ws + L.scores);
     const float *scores_eff = activation == ACT_NONE ? scores : scores_ws;
 
@@ -1813,7 +1787,7 @@ extern "C" int detbox_select_decode(int decode_mode, int activation, const float
     sp.tile_anchors = (int)tile;
     const int64_t tiles = (P + tile - 1) / tile;
     sp.use_sample = plan.use_sample; sp.sample_rate = plan.rate; sp.sample_m = plan.m;
-    sp.n_sub = plan.n_sub; sp.ns_cap = plan.ns_cap; sp.blk_cap = plan.blk_cap;
+    sp.n_sub = plan.n_sub; sp.ns_cap = plan.ns_cap;
     sp.subs_per_block = plan.subs_per_block; sp.scan_gx = plan.scan_gx;
     sp.tile_floats = tile_floats_for(C);
     sp.total_floats = (long long)B * P * C;
@@ -1853,7 +1827,7 @@ extern "C" int detbox_select_decode(int decode_mode, int activation, const float
     {
         FastArgs a;
         a.in = scores; a.extra = extra; a.sp = sp; a.B = B; a.flag = flag; a.cnt = cnt; a.img_ovf = img_ovf; a.hist = ghist;
-        a.blk_cnt = blk_cnt; a.rules = rules; a.staging = staging; a.blk_list = blk_list; a.samp = samp;
+        a.rules = rules; a.staging = staging; a.samp = samp;
         a.scores_ws = scores_ws; a.s = s;
         if (int rc = dispatch_act_ept<LaunchFast>(activation, ept_for(C), a)) return rc;
     }
