@@ -84,13 +84,18 @@ def synth_head(i, P, C, family, regime):
 
 
 class Workload:
-    def __init__(self, name, regime, rank, dev):
+    def __init__(self, name, regime, rank, dev, exact=False):
         w = WORKLOADS[name]
         self.name, self.regime, self.w, self.dev = name, regime, w, dev
         self.exchange = None
         self.exchange_root = 0          # the evaluator is one process (rank 0), as in the reference's test loop
+        self.exchange_payload = 'rows'
         self.model = w['make']()
         m = self.model
+        # exact: torch's own activation on the device, then the selection on those very bits (the mode whose candidate
+        # sets are bit-exact against a torch build); default: the activation fused into the selection pass
+        self.exact = exact
+        m.fused_activation = not exact
         self.anchors_cpu = m._anchors_for_decode()
         self.P = self.anchors_cpu.shape[0]
         self.B, self.C, self.top_k = w['B'], w['C'], w['top_k']
@@ -151,7 +156,8 @@ class Workload:
             # the exchange step: this rank's detections as a compact message; the gather of the previous
             # batch's messages starts now, on a side stream, and overlaps this batch's kernels
             if self.exchange is None:
-                self.exchange = RowExchange(keep_results=False, root=self.exchange_root)
+                self.exchange = RowExchange(keep_results=False, root=self.exchange_root, payload=self.exchange_payload,
+                                            timing=True)
                 self.hdr_rows = ops.wire_header_rows(self.B)
             keep, kc, rows_ids, rows_vals, row_off, wire = ops.nms_rows(c, 0.45, self.ids, self.hw, wire_images_cap=self.B)
             self.exchange.submit(wire, self.B, self.hdr_rows)
@@ -185,19 +191,28 @@ def cpu_baseline(wl, n_img):
     return n_img / dt, dt, len(res)
 
 
+def counters_current(entry_sha):
+    """True when a committed counter pass was taken on the kernel sources this run was built from."""
+    from object_detection_amd.build import source_hash
+    return entry_sha is not None and entry_sha == source_hash()
+
+
 def measured_traffic(workload, regime, kernel):
     """HBM bytes per launch of `kernel` from the committed counter passes (profiles/traffic.json, written
-    by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command), or None."""
+    by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command), or None -- also when the
+    pass was taken on other kernel sources than the ones built now (stale counters never reach the line)."""
     try:
         with open(os.path.join(REPO, 'profiles', 'traffic.json')) as f:
-            t = json.load(f)
-        return t[f'{workload}/{regime}'][kernel]['hbm_bytes_per_launch']
+            t = json.load(f)[f'{workload}/{regime}']
+        if not counters_current(t.get('_source_sha256')):
+            return None
+        return t[kernel]['hbm_bytes_per_launch']
     except (OSError, KeyError, ValueError):
         return None
 
 
 KERNELS = ['assign_anchor', 'assign_fixup', 'assign_fcos', 'select_sample', 'select_plan', 'select_scan',
-           'select_bucket', 'select_check', 'select_fallback', 'select_materialize', 'score_hist', 'select_kth',
+           'select_check', 'select_fallback', 'select_materialize', 'score_hist', 'select_kth',
            'select_refine', 'select_emit', 'select_finalize', 'select_direct_stats', 'select_direct', 'nms_segments', 'nms_scan', 'nms_merge',
            'nms_split', 'nms_tile', 'pack_detections']
 PRICED = ('select_scan', 'score_hist', 'select_emit', 'assign_anchor', 'assign_fcos', 'nms_segments', 'select_finalize',
@@ -220,6 +235,8 @@ def parse_args(argv=None):
                     help='N=1 only: capture one step per stream in a HIP graph and replay it in the timed region (launch-bound workloads)')
     ap.add_argument('--streams', type=int, default=3,
                     help='steps are issued round-robin on this many HIP streams (independent batches in flight)')
+    ap.add_argument('--exchange-payload', default='rows', choices=['rows', 'header'],
+                    help='N>1: what every rank ships: its detections, or only the per-image row counts (a consumer that needs no boxes)')
     ap.add_argument('--exchange', default='all', choices=['all', 'root'],
                     help='N>1: every rank receives the detections of all ranks (all-gather), or only rank 0 does (gather)')
     return ap.parse_args(argv)
@@ -370,12 +387,11 @@ def price(wl, m, world, steps):
                          'batch in flight; avg_us_one_batch_in_flight comes from the single-stream survey pass')
     if dom == 'nms_segments':
         # greedy NMS is O(n * kept) pair tests on data that stays on chip: VALU issue, not HBM, is what it can
-        # saturate.  valu_frac = VALU wave-instructions x 4 cycles / (SIMDs x kernel cycles), from the committed
-        # counter pass of this command (profiles/), scaled to the duration measured here.
+        # saturate.  valu_frac = VALU wave-instructions per second (committed counter pass of this command, profiles/,
+        # over the duration measured here) / the chip's measured issue peak (tools/bw/exp_valu.hip).
         v = measured_valu(wl.name, wl.regime)
         if v is not None:
-            roofline['valu_frac'] = v['valu_insts_per_launch'] * 4.0 / (v['simds'] * v['clock_mhz'] * m['dom_us'])
-            roofline['valu_insts_per_launch'] = v['valu_insts_per_launch']
+            roofline.update(valu_fields(v, m['dom_us']))
     streaming = None
     if 'select_scan' in kern:
         a = score_bytes / (kern['select_scan']['avg_us'] * 1e-6) / 1e9
@@ -393,12 +409,11 @@ def price(wl, m, world, steps):
                      traffic=measured_traffic(wl.name, wl.regime, 'nms_segments'), avg_us=us,
                      algorithmic_bytes=alg_bytes['nms_segments'],
                      note='survey pass; O(n * kept) pair tests on data that stays on chip: HBM frac is reported for '
-                          'completeness, valu_frac (VALU wave-instructions x 4 cycles / (SIMDs x kernel cycles), '
-                          'committed counter pass) is the yardstick')
+                          'completeness, valu_frac (VALU wave-instructions per second / measured issue peak of the chip, '
+                          'committed counter pass and microbenchmark) is the yardstick')
         v = measured_valu(wl.name, wl.regime)
         if v is not None:
-            pairs['valu_frac'] = v['valu_insts_per_launch'] * 4.0 / (v['simds'] * v['clock_mhz'] * us)
-            pairs['valu_insts_per_launch'] = v['valu_insts_per_launch']
+            pairs.update(valu_fields(v, us))
     anchor_bytes = {'fcos': 8, 'yolo': 20}.get(wl.w['family'], 16)
     bytes_img = ((52.0 if wl.w['family'] == 'fcos' else 48.0) * P + 24.0 * G_mean
                  + 4.0 * P * C + 16.0 * P + anchor_bytes * P + (4.0 * P if wl.ext is not None else 0.0) + 28.0 * n_cand
@@ -415,11 +430,39 @@ def price(wl, m, world, steps):
 
 
 def measured_valu(workload, regime):
+    """The committed SQ counter pass of the NMS kernel (profiles/valu.json), or None when it is missing or was taken on
+    other kernel sources than the ones built now."""
     try:
         with open(os.path.join(REPO, 'profiles', 'valu.json')) as f:
-            return json.load(f)[f'{workload}/{regime}']['nms_segments']
+            v = json.load(f)[f'{workload}/{regime}']['nms_segments']
+        return v if counters_current(v.get('source_sha256')) else None
     except (OSError, KeyError, ValueError):
         return None
+
+
+def valu_peaks():
+    """Measured VALU issue peaks of the chip in wave-instructions per second (profiles/valu_peak.json, from
+    tools/bw/exp_valu.hip): plain 32-bit instructions, and the half-rate ones the NMS pair filter is made of."""
+    try:
+        with open(os.path.join(REPO, 'profiles', 'valu_peak.json')) as f:
+            p = json.load(f)
+        return float(p['plain_wave_insts_per_s']), float(p['half_rate_wave_insts_per_s'])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def valu_fields(v, us):
+    """VALU issue share of a kernel that ran `us` microseconds: its wave-instructions per second against the measured
+    peak for plain instructions (a lower bound of the share: every instruction priced as a full-rate one) and against
+    the peak for half-rate ones (an upper bound)."""
+    out = {'valu_insts_per_launch': v['valu_insts_per_launch']}
+    pk = valu_peaks()
+    if pk is not None:
+        rate = v['valu_insts_per_launch'] / (us * 1e-6)
+        out['valu_frac'] = rate / pk[0]
+        out['valu_frac_if_all_half_rate'] = rate / pk[1]
+        out['valu_peak_wave_insts_per_s'] = {'plain': pk[0], 'half_rate': pk[1]}
+    return out
 
 
 def main():
@@ -451,10 +494,28 @@ def main():
 
     wl = Workload(args.workload, args.regime, rank, dev)
     wl.exchange_root = 0 if args.exchange == 'root' else None
+    wl.exchange_payload = args.exchange_payload
     B, P, C = wl.B, wl.P, wl.C
     m = measure(wl, args, world, dist, args.steps, args.warmup, args.blocks, args.streams, args.graph)
     host_waits = wl.exchange.host_waits if wl.exchange is not None else None
     gt_mean = wl.total_gt / B
+    exchange = None
+    if wl.exchange is not None:
+        # what the exchange asks of the links, next to what the kernels ask of the chip: bytes INTO this rank per step,
+        # the time its gathers took on the side stream (events; device collectives only), and the rate that would hide
+        # them behind a step.  A GPU's seven xGMI links carry 7 x 76.8 GB/s in one direction at their peak.
+        ex = wl.exchange
+        n_g = max(ex.gathers, 1)
+        bytes_in = ex.gather_bytes_in / n_g
+        ms = ex.gather_ms / n_g if ex.gather_ms > 0 else None
+        peak = 7 * 76.8
+        exchange = dict(collective='gather to rank 0' if args.exchange == 'root' else 'all-gather', payload=args.exchange_payload,
+                        bytes_in_per_step_per_rank=bytes_in, gather_ms_per_step=ms, batches_measured=ex.gathers,
+                        roofline=dict(bound='xgmi', peak=peak, unit='GB/s',
+                                      achieved=(bytes_in / (ms * 1e-3) / 1e9 if ms else None),
+                                      frac=(bytes_in / (ms * 1e-3) / 1e9 / peak if ms else None),
+                                      note='peak = 7 links x 76.8 GB/s into one GPU; achieved = bytes received by rank 0 per batch '
+                                           '/ time of its gather on the side stream'))
 
     if rank == 0:
         pr = price(wl, m, world, args.steps)
@@ -474,16 +535,22 @@ def main():
             torch.cuda.empty_cache()
             # graph replay where the host's launch rate is what binds (issuing a stage twice costs more than the
             # stage's kernels take: tools/twice.sh): the small workload and the trained-like regime
-            for name, regime, steps, graph in (('ssd300', 'dense', 200, True), ('ssd300_b512', 'dense', 20, False),
-                                               ('retinanet800', 'trained', 50, True), ('ssd300_b512', 'trained', 50, True),
-                                               ('fcos800', 'dense', 100, True), ('yolov3', 'dense', 100, True)):
-                if name == args.workload and regime == args.regime:
+            # sparse: the survey's second regime (+8 on the background column / -6 on the objectness).  exact: the same dense
+            # workload with torch's own activation instead of the fused one -- the mode whose keep lists are bit-exact.
+            for name, regime, steps, graph, exact in (
+                    ('ssd300', 'dense', 200, True, False), ('ssd300_b512', 'dense', 20, False, False),
+                    ('retinanet800', 'sparse', 20, False, False), ('ssd300_b512', 'sparse', 20, False, False),
+                    ('retinanet800', 'trained', 50, True, False), ('ssd300_b512', 'trained', 50, True, False),
+                    ('retinanet800', 'dense', 20, False, True), ('ssd300_b512', 'dense', 20, False, True),
+                    ('fcos800', 'dense', 100, True, False), ('yolov3', 'dense', 100, True, False)):
+                if name == args.workload and regime == args.regime and not exact:
                     continue
-                w2 = Workload(name, regime, 0, dev)
+                w2 = Workload(name, regime, 0, dev, exact=exact)
                 m2 = measure(w2, args, 1, None, steps, 3, 5, args.streams, graph)
                 p2 = price(w2, m2, 1, steps)
-                extra[f'{name}/{regime}'] = {
+                extra[f'{name}/{regime}' + ('/exact' if exact else '')] = {
                     'images_per_s': p2['ips'], 'ms_per_step': p2['ms_per_step'], 'images_per_gpu': w2.B,
+                    'activation': 'torch on the device, then the selection (bit-exact candidate sets)' if exact else 'fused into the selection pass',
                     'hbm_frac_whole_step': p2['hbm_frac'], 'algorithmic_bytes_per_image': p2['bytes_img'],
                     'candidates_per_image': m2['n_cand'], 'kept_per_image': m2['n_keep'], 'launch': m2['launch'],
                     'dominant_kernel': m2['dom'], 'dominant_avg_us': round(m2['kern'][m2['dom']]['avg_us'], 2),
@@ -502,6 +569,8 @@ def main():
                        'streams': m['streams'],
                        'exchange': ('none' if world == 1 else ('gather to rank 0' if args.exchange == 'root' else 'all-gather')),
                        'exchange_host_waits': host_waits},
+            'exchange': (dict(exchange, rate_to_hide_behind_a_step_GBps=exchange['bytes_in_per_step_per_rank'] / (pr['ms_per_step'] * 1e-3) / 1e9)
+                         if exchange is not None else None),
             'blocks': pr['blocks'],
             'roofline': pr['roofline'],
             'roofline_streaming': pr['streaming'],

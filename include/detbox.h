@@ -268,7 +268,7 @@ int detbox_pack_detections_wire(const float *boxes, const float *scores, const i
  * detbox_profile_read synchronises those events and returns the accumulated time and launch
  * count of the kernel called `name`; reset drops all samples.  Kernel names: "box_convert",
  * "box_iou", "assign_anchor", "assign_fixup", "assign_fcos", "activate_scores", "select_sample",
- * "select_plan", "select_scan", "select_bucket", "select_check", "select_materialize", "score_hist", "select_kth",
+ * "select_plan", "select_scan", "select_check", "select_materialize", "score_hist", "select_kth",
  * "select_refine", "select_emit", "select_finalize", "select_direct_stats", "select_direct", "nms_segments", "nms_scan", "nms_merge",
  * "nms_split", "nms_tile", "pack_detections", "pack_wire", "topk_mask", "focal_forward", "focal_backward",
  * "smooth_l1_forward", "smooth_l1_backward". */

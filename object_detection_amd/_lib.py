@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdetbox.so')
+# DETBOX_LIB: another build of the same library (experiments); the default is the in-tree build
+LIB_PATH = os.environ.get('DETBOX_LIB') or os.path.join(_HERE, 'libdetbox.so')
 
 _p, _i64, _i32, _f32, _f64, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
                                    ctypes.c_double, ctypes.c_size_t)

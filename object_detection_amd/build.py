@@ -22,6 +22,16 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
 
+def source_hash():
+    """sha256 over the kernel sources and the C header: identifies the code a counter pass was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sources() + sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(HERE, '..', 'include', 'detbox.h')]:
+        with open(path, 'rb') as f:
+            h.update(os.path.basename(path).encode() + b'\0' + f.read())
+    return h.hexdigest()
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True

@@ -36,10 +36,10 @@ struct Carver {
 
 // ---- order step of the batched NMS + result rows (merge.hip), driven from nms.hip -----------------------------
 // How the kept runs of one image are cut into tiles: every SP-th run element is a sample, every Q-th merged sample a
-// splitter, at most T_max tiles per image.  ok == false: the shape is outside what the tile kernels hold
+// splitter, at most T_max tiles per image; an image of at most one_tile_rows kept rows is not cut.  ok == false: the shape is outside what the tile kernels hold
 // (more than 256 segments per image, or tiles that would not fit) and the caller takes the level-by-level merge.
-struct MergePlan { bool ok; int SP, Q, T_max; };
-MergePlan merge_plan(int64_t stride, int64_t S);
+struct MergePlan { bool ok; int SP, Q, T_max, one_tile_rows; };
+MergePlan merge_plan(int64_t B, int64_t stride, int64_t S);
 size_t merge_workspace_bytes(const MergePlan &p, int64_t B, int64_t S);
 
 // Where the result rows go (all device pointers; wire may be null).

@@ -225,7 +225,7 @@ __device__ inline bool bucket_sort(u64 *__restrict__ a, u64 *__restrict__ b, con
 
 __global__ __launch_bounds__(MG_SPLIT_THREADS) void nms_split_kernel(
     const float2 *__restrict__ kept, const int32_t *__restrict__ kcount, const int32_t *__restrict__ seg_off,
-    const int S, const long long stride, const int SP, const int Q, const int T_max,
+    const int S, const long long stride, const int SP, const int Q, const int T_max, const int one_tile_rows,
     int32_t *__restrict__ keep_counts, int32_t *__restrict__ csmat, u64 *__restrict__ kmat, int32_t *__restrict__ ntiles,
     const int stats) {
     extern __shared__ u64 s_dyn[];
@@ -250,11 +250,11 @@ __global__ __launch_bounds__(MG_SPLIT_THREADS) void nms_split_kernel(
     if (tid == 0) s_soff[S] = (int)nsamp;
     __syncthreads();
     if (tid == 0) keep_counts[b] = s_bad ? -1 : (int)n;
-    if (n <= (uint32_t)MG_CAP) {                 // the whole image is one tile
+    if (n <= (uint32_t)one_tile_rows) {          // the whole image is one tile (one_tile_rows >= SP * Q)
         if (tid == 0) ntiles[b] = 1;
         return;
     }
-    const int T = (int)((nsamp + Q - 1) / Q);    // >= 2: nsamp * SP >= n > MG_CAP >= SP * Q
+    const int T = (int)((nsamp + Q - 1) / Q);    // >= 2: nsamp * SP >= n > SP * Q
     if (tid == 0) ntiles[b] = T;
     u64 *buf_a = s_dyn, *buf_b = s_dyn + MG_NS_CAP;
     const float2 *kb = kept + (size_t)b * stride;
@@ -360,11 +360,12 @@ __global__ __launch_bounds__(MG_TILE_THREADS) void nms_tile_kernel(
     double W = 0.0, H = 0.0;
     long long img_id = 0;
     if (ROWS) {
-        for (int i = tid; i < b; i += THREADS) rows_before += (uint32_t)max(keep_counts[i], 0);
         n_img = max(keep_counts[b], 0);                  // a flagged image has a keep list but no rows
         W = (double)image_sizes[2 * b + 1]; H = (double)image_sizes[2 * b]; img_id = image_ids[b];
     }
-    if (t >= T) return;
+    if (t >= T) return;                                  // a workgroup beyond the image's tiles has issued a dozen loads, no more
+    if (ROWS)
+        for (int i = tid; i < b; i += THREADS) rows_before += (uint32_t)max(keep_counts[i], 0);
     if (tid < S) {
         k_run = max(k_run, 0);
         s_k[tid] = k_run;
@@ -570,20 +571,27 @@ extern "C" int detbox_debug_merge_stats(uint64_t *out8, int enable, int reset) {
 
 namespace detbox {
 
-MergePlan merge_plan(int64_t stride, int64_t S) {
+MergePlan merge_plan(int64_t B, int64_t stride, int64_t S) {
     MergePlan p;
-    p.ok = false; p.SP = 64; p.Q = 1; p.T_max = 1;
-    if (S < 1 || S > MG_MAX_S || stride < 1) return p;
-    if (stride <= MG_CAP) { p.ok = true; return p; }
+    p.ok = false; p.SP = 64; p.Q = 1; p.T_max = 1; p.one_tile_rows = MG_CAP;
+    if (S < 1 || S > MG_MAX_S || stride < 1 || B < 1) return p;
     int SP = 8;
     while (stride / SP + S > MG_NS_CAP && SP < 64) SP *= 2;
     if (stride / SP + S > MG_NS_CAP) return p;
     const int64_t err = (int64_t)(SP - 1) * S;
     if (MG_CAP - err < 8 * SP) return p;
-    const int Q = (int)((MG_CAP - err) / SP);
-    const int64_t T_max = (stride / SP + S + Q - 1) / Q;
+    // Rows per tile: as many as a workgroup holds when there are rows enough to fill the chip that way; with fewer rows
+    // (few images, short keep lists) smaller tiles, so that about two workgroups per CU share the work, down to 512 rows.
+    int64_t target = B * stride / 480;
+    if (target < 512) target = 512;
+    if (target > MG_CAP - err) target = MG_CAP - err;
+    const int Q = (int)(target / SP) > 0 ? (int)(target / SP) : 1;
+    // An image is cut only if that buys parallelism: with about two images per CU or more, one that fits a workgroup
+    // stays whole.
+    const int one = B >= 480 ? MG_CAP : SP * Q;
+    const int64_t T_max = stride <= one ? 1 : (stride / SP + S + Q - 1) / Q;
     if (T_max * S > MG_HIST_CAP) return p;
-    p.ok = true; p.SP = SP; p.Q = Q; p.T_max = (int)T_max;
+    p.ok = true; p.SP = SP; p.Q = Q; p.T_max = (int)T_max; p.one_tile_rows = one;
     return p;
 }
 
@@ -599,7 +607,7 @@ int merge_rows_launch(const MergePlan &p, const float2 *kept, const int32_t *kco
         DETBOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_split_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         nms_split_kernel<<<dim3((unsigned)B), dim3(MG_SPLIT_THREADS), lds, st>>>(kept, kcount, seg_offsets, (int)S, stride, p.SP, p.Q,
-                                                                          p.T_max, keep_counts, w.csmat, w.kmat, w.ntiles, g_merge_stats_on ? 1 : 0);
+                                                                          p.T_max, p.one_tile_rows, keep_counts, w.csmat, w.kmat, w.ntiles, g_merge_stats_on ? 1 : 0);
         DETBOX_LAUNCH_CHECK();
     }
     {

@@ -1597,8 +1597,8 @@ struct NmsLayout { size_t kept_a, kept_b, kcount, koff, merge, total; };
 // DETBOX_NMS_LEVEL_MERGE=1 (measurements, tests): always the level-by-level merge, never the tile merge
 bool g_nms_level_merge = std::getenv("DETBOX_NMS_LEVEL_MERGE") != nullptr;     // also switched by detbox_debug_nms_level_merge
 
-MergePlan nms_merge_plan(int64_t stride, int64_t S) {
-    MergePlan p = merge_plan(stride, S);
+MergePlan nms_merge_plan(int64_t B, int64_t stride, int64_t S) {
+    MergePlan p = merge_plan(B, stride, S);
     if (g_nms_level_merge) p.ok = false;
     return p;
 }
@@ -1606,7 +1606,7 @@ MergePlan nms_merge_plan(int64_t stride, int64_t S) {
 // The tile merge reads the kept runs once and needs no second run buffer; the level-by-level merge ping-pongs.
 NmsLayout nms_layout(int64_t B, int64_t stride, int64_t S) {
     NmsLayout L;
-    const MergePlan p = nms_merge_plan(stride, S);
+    const MergePlan p = nms_merge_plan(B, stride, S);
     size_t off = 0;
     L.kept_a = off; off = align_up(off + (size_t)B * stride * sizeof(float2), 256);
     L.kept_b = off; off = align_up(off + (p.ok ? 0 : (size_t)B * stride * sizeof(float2)), 256);
@@ -1733,7 +1733,7 @@ int nms_run(const float *boxes, const float *scores, const int32_t *seg_offsets,
         }
         DETBOX_LAUNCH_CHECK();
     }
-    const MergePlan plan = nms_merge_plan(stride, S);
+    const MergePlan plan = nms_merge_plan(B, stride, S);
     if (plan.ok) {
         if (rows_done) *rows_done = rows != nullptr;
         return merge_rows_launch(plan, kept_a, kcount, seg_offsets, B, stride, S, keep, keep_counts, rows, ws + L.merge, st);

@@ -46,7 +46,7 @@ constexpr int SCAN_BLOCK = 256;
 constexpr int LPR = 4;                // lanes that share one anchor row (8, with 512 threads, was measured: no faster)
 constexpr int SUB_ROWS = SCAN_BLOCK / LPR;   // anchors per LDS sub-tile
 constexpr int SCAN_WAVES = SCAN_BLOCK / 64;  // every wave of a scan workgroup keeps its own candidate list
-constexpr int SCAN_EBUF = 256;        // entries of a scan wave's staging buffer in LDS
+constexpr int SCAN_EBUF = 256;        // most entries of one of a scan wave's two candidate lists in LDS (sp.ebuf: 128 or 256)
 constexpr int SAMPLE_SUBS = 4;        // sampled sub-tiles per workgroup of select_sample
 constexpr int BITMAP_MAX_WORDS = 4096;  // finalize orders by anchor through a P-bit LDS bitmap up to this
 
@@ -66,7 +66,7 @@ struct SelRule {
 struct SelParams {
     int P, C, cb, Cs, top_k, cap, shift, tile_anchors;
     int use_sample, sample_rate, sample_m, subs_per_block, n_sub, tile_floats;
-    int ns_cap, scan_gx;
+    int ns_cap, scan_gx, ebuf;
     long long total_floats;
     float thr;
     uint32_t key_thr;
@@ -107,6 +107,13 @@ __device__ inline float quad_sum_from(float v) {
 __device__ inline float quad_max(float v) { return quad_max_from<1>(v); }
 __device__ inline float quad_sum(float v) { return quad_sum_from<1>(v); }
 __device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// exp of the soft-max: the hardware's exp2 with a scaled argument (2 ulp), or, built with DETBOX_SOFTMAX_LIBM_EXP, the
+// library's expf (1 ulp, about three times the instructions)
+#ifdef DETBOX_SOFTMAX_LIBM_EXP
+__device__ inline float softmax_exp(float x) { return expf(x); }
+#else
+__device__ inline float softmax_exp(float x) { return __expf(x); }
+#endif
 
 // One sub-tile = rows [row_base, row_base+rows) x C of the head output.  It is brought into LDS by
 // LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, no staging registers); the LDS
@@ -164,8 +171,8 @@ struct RowCtx {
 template <int ACT>
 __device__ inline float rescore(const RowCtx &c, int i) {
     const float v = c.row[LPR * i];
-    if (ACT == ACT_SOFTMAX) return __expf(v - c.m) * c.inv;
-    if (ACT == ACT_SOFTMAX_SIGMOID) return (__expf(v - c.m) * c.inv) * c.sg;
+    if (ACT == ACT_SOFTMAX) return softmax_exp(v - c.m) * c.inv;
+    if (ACT == ACT_SOFTMAX_SIGMOID) return (softmax_exp(v - c.m) * c.inv) * c.sg;
     if (ACT == ACT_SIGMOID_SIGMOID) return sigmoidf_(v) * c.sg;
     return v;
 }
@@ -194,7 +201,7 @@ __device__ inline bool subtile_scores(const float *s_tile, const float *__restri
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
-            x[i] = __expf(x[i] - m);
+            x[i] = softmax_exp(x[i] - m);
             sum += x[i];
         }
         sum = quad_sum(sum);
@@ -560,7 +567,6 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
                                                                  uint32_t *__restrict__ gcnt,
                                                                  unsigned long long *__restrict__ staging) {
     extern __shared__ float s_dynf[];
-    __shared__ uint32_t s_wc[SCAN_WAVES][MAX_SEL_CLASSES];     // per wave: entries per class of the list being flushed, then their bases
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int Cs = sp.Cs, cb = sp.cb, C = sp.C;
     const uint32_t key_thr = sp.key_thr;
@@ -571,16 +577,22 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
     // two sub-tiles -- the atomics are issued behind one barrier, their results used behind the next, which waits for
     // the sub-tile's DMA anyway -- and the wave fills its second list meanwhile, so nothing ever waits for an atomic.
     const int wv = tid >> 6;
-    uint32_t *wc = s_wc[wv];
-    unsigned long long *ebuf0 = reinterpret_cast<unsigned long long *>(s_dynf + 2 * (size_t)sp.tile_floats + 4) + (size_t)wv * 2 * SCAN_EBUF;
-    unsigned long long *ebuf = ebuf0, *pbuf = ebuf0 + SCAN_EBUF;
+    const uint32_t ebuf_n = (uint32_t)sp.ebuf;            // entries per list: 256, or 128 where the sub-tiles are small and
+                                                          // more workgroups share a CU
+    const bool two_rows = Cs > 64;                        // classes 64.. exist: a lane looks after class lane and class lane + 64
+    unsigned long long *ebuf0 = reinterpret_cast<unsigned long long *>(s_dynf + 2 * (size_t)sp.tile_floats + 4) + (size_t)wv * 2 * ebuf_n;
+    unsigned long long *ebuf = ebuf0, *pbuf = ebuf0 + ebuf_n;
+    // per wave, behind the lists: entries per class of the list being handed over, then their bases
+    uint32_t *wc = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned long long *>(s_dynf + 2 * (size_t)sp.tile_floats + 4) + (size_t)SCAN_WAVES * 2 * ebuf_n)
+                   + (size_t)wv * (two_rows ? 128 : 64);
     unsigned long long *stg = staging + (size_t)b * Cs * sp.cap;
     uint32_t *gc = gcnt + (size_t)b * Cs;
     const uint32_t cap = (uint32_t)sp.cap;
     uint32_t ln = 0, pn = 0;                              // entries waiting in the current list; entries of the list being handed over
     uint32_t pmeta[SCAN_EBUF / 64], gbase0 = 0, gbase1 = 0;
     auto flush_begin = [&]() {                            // pn == 0
-        wc[lane] = 0u; wc[lane + 64] = 0u;
+        wc[lane] = 0u;
+        if (two_rows) wc[lane + 64] = 0u;
 #pragma unroll
         for (int j = 0; j < SCAN_EBUF / 64; ++j) {
             const uint32_t k = (uint32_t)lane + 64u * j;
@@ -590,7 +602,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
                 pmeta[j] = (ci << 16) | atomicAdd(&wc[ci], 1u);           // place among the list's entries of that class
             }
         }
-        const uint32_t c0 = wc[lane], c1 = wc[lane + 64];
+        const uint32_t c0 = wc[lane], c1 = two_rows ? wc[lane + 64] : 0u;
         gbase0 = c0 ? atomicAdd(&gc[lane], c0) : 0u;                      // c0 != 0 only for lane < Cs
         gbase1 = c1 ? atomicAdd(&gc[lane + 64], c1) : 0u;
         unsigned long long *t = ebuf; ebuf = pbuf; pbuf = t;
@@ -599,7 +611,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
     };
     auto flush_end = [&]() {
         if (pn == 0u) return;
-        wc[lane] = gbase0; wc[lane + 64] = gbase1;
+        wc[lane] = gbase0;
+        if (two_rows) wc[lane + 64] = gbase1;
 #pragma unroll
         for (int j = 0; j < SCAN_EBUF / 64; ++j) {
             const uint32_t k = (uint32_t)lane + 64u * j;
@@ -658,8 +671,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
             if (__ballot(cnt != 0u) != 0ull) {
                 const uint32_t inc = wave_inclusive_add(cnt);
                 const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-                if (total <= (uint32_t)SCAN_EBUF) {
-                    if (ln + total > (uint32_t)SCAN_EBUF) flush();
+                if (total <= ebuf_n) {
+                    if (ln + total > ebuf_n) flush();
                     uint32_t slot = ln + inc - cnt;
                     auto put = [&](int i) {
                         const float sc = rescore<ACT>(ctx, i);               // same arithmetic as x[i], bit for bit
@@ -683,7 +696,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
                     unsigned long long pm = ((unsigned long long)pm_hi << 32) | pm_lo;
                     unsigned long long has = __ballot(pm != 0ull);
                     while (has) {
-                        if (ln + 64u > (uint32_t)SCAN_EBUF) flush();
+                        if (ln + 64u > ebuf_n) flush();
                         if (pm) {
                             const uint32_t slot = ln + __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0u));
                             const int i = __ffsll((long long)pm) - 1;
@@ -700,7 +713,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
         // behind the barrier: the atomics and the stores have the whole next sub-tile to complete before a barrier waits for them
         [&](long long) {
             flush_end();
-            if (ln >= (uint32_t)SCAN_EBUF / 2u) flush_begin();
+            if (ln >= ebuf_n / 2u) flush_begin();
         }, fetch_thresholds, load_thresholds);
     flush();
 }
@@ -1428,8 +1441,18 @@ int ept_for(int64_t C) { return (C <= 32 ? 32 : (C <= 96 ? 96 : (C <= 128 ? 128 
 // unconditional register loads of the activation stay inside the buffer.
 int tile_floats_for(int64_t C) { return (int)(((SUB_ROWS * C + LPR * ept_for(C) + 8) / 4 + 1) * 4); }
 
+// Entries of each of a scan wave's two candidate lists: 256, or 128 where the sub-tiles are small (few classes), many
+// workgroups share a CU and the lists would otherwise be most of a workgroup's LDS.
+int scan_ebuf_for(int64_t C) { return (size_t)tile_floats_for(C) * 4 >= 16 * 1024 ? 256 : 128; }
+
+// LDS bytes of a scan workgroup: two sub-tile buffers, the waves' candidate lists, their per-class counters.
+size_t scan_lds_bytes(int64_t C, int64_t Cs) {
+    return 2 * (size_t)tile_floats_for(C) * 4 + 16 + (size_t)SCAN_WAVES * 2 * scan_ebuf_for(C) * 8 +
+           (size_t)SCAN_WAVES * (Cs > 64 ? 128 : 64) * sizeof(uint32_t);
+}
+
 // Workgroups of the scan that are resident at once: LDS-limited, on every CU of the device.
-int64_t scan_resident_workgroups(int64_t C) {
+int64_t scan_resident_workgroups(int64_t C, int64_t Cs) {
     static int cus[64] = {0};                                     // per device; a racing first call writes the same value
     // One sub-tile per workgroup is in flight, and about 40 KB in flight per CU keep the DMA pipeline at its rate (two
     // workgroups at C = 81, eight at C = 21; a third workgroup at C = 81 adds 1 % to the scan on its own).  The LDS left
@@ -1444,7 +1467,7 @@ int64_t scan_resident_workgroups(int64_t C) {
         cus[dev] = n;
     }
     const size_t tile = (size_t)tile_floats_for(C) * 4;
-    const size_t lds = 2 * tile + 16 + (size_t)(SCAN_BLOCK / 64) * 2 * SCAN_EBUF * 8 + sizeof(uint32_t) * SCAN_WAVES * MAX_SEL_CLASSES;
+    const size_t lds = scan_lds_bytes(C, Cs) + sizeof(float) * MAX_SEL_CLASSES;      // + the thresholds (static)
     int64_t per_cu = (int64_t)((160 * 1024) / lds);
     const int64_t want = per_cu_env ? per_cu_env : (int64_t)((40 * 1024 + tile - 1) / tile);
     if (per_cu > want) per_cu = want;
@@ -1461,7 +1484,7 @@ SelPlan make_plan(int64_t B, int64_t P, int64_t C, int64_t Cs, int top_k) {
     // Whole rounds of resident workgroups: a partly filled round costs as much as a full one.  With gx
     // workgroups per image the scan takes ceil(B*gx / resident) rounds of ceil(n_sub / gx) sub-tiles each;
     // take the gx that minimises the product.
-    const int64_t resident = scan_resident_workgroups(C);
+    const int64_t resident = scan_resident_workgroups(C, Cs);
     int64_t best_cost = -1, spb = sp.n_sub;
     for (int64_t r = 1; r <= 8; ++r) {
         int64_t gx = (r * resident) / (B > 0 ? B : 1);
@@ -1589,7 +1612,7 @@ struct LaunchFast {
         }
         const unsigned gx = (unsigned)sp.scan_gx;
         if (sp.use_sample) {
-            const size_t lds = 2 * tile_bytes + 16 + (size_t)(SCAN_BLOCK / 64) * 2 * SCAN_EBUF * 8;
+            const size_t lds = scan_lds_bytes(sp.C, sp.Cs);
             if (int rc = set_lds(select_scan_kernel<ACT, EPT>, lds)) return rc;
             {
                 ProfScope ps("select_scan", s);
@@ -1790,6 +1813,7 @@ extern "C" int detbox_select_decode(int decode_mode, int activation, const float
     sp.n_sub = plan.n_sub; sp.ns_cap = plan.ns_cap;
     sp.subs_per_block = plan.subs_per_block; sp.scan_gx = plan.scan_gx;
     sp.tile_floats = tile_floats_for(C);
+    sp.ebuf = scan_ebuf_for(C);
     sp.total_floats = (long long)B * P * C;
 
     if (use_direct(B, P, C)) {
@@ -1908,7 +1932,7 @@ template <int ACT, int EPT>
 struct LaunchFocal {
     static int run(const FocalArgs &a) {
         const int n_sub = (int)((a.rows + SUB_ROWS - 1) / SUB_ROWS);
-        const int64_t resident = scan_resident_workgroups(a.C);
+        const int64_t resident = scan_resident_workgroups(a.C, a.C);
         int spb = (int)((n_sub + resident - 1) / resident);
         if (spb < 1) spb = 1;
         const unsigned gx = (unsigned)((n_sub + spb - 1) / spb);

@@ -91,23 +91,42 @@ class RowExchange:
     the pipeline and waits for every gather.  Works on gloo / CPU tensors too (no streams there; messages on a
     GPU are staged through the host for a backend that cannot move device memory).
 
-    root=None: every rank receives every message (all-gather: the path's one collective).  root=r: only global
-    rank r receives them (gather) -- enough for a single evaluator process (src/test.py:98-99 builds one list in
-    one process).  The mode is fixed at construction; a backend that lacks the collective raises."""
+    root=None: every rank receives every message (all-gather: the path's one collective).  root=r: only the rank
+    whose GLOBAL rank is r receives them (gather) -- enough for a single evaluator process (src/test.py:98-99 builds
+    one list in one process); r must belong to `group`.  The mode is fixed at construction; a backend that lacks the
+    collective raises.
 
-    def __init__(self, group=None, keep_results: bool = True, root=None):
+    payload='rows' (default): the detections travel.  payload='header': only the header of every message does (row
+    count and row offsets per image, image ids and sizes: 24 bytes per image instead of 24 bytes per detection) --
+    for a consumer that tallies detections per image and needs no boxes.
+
+    submit() takes the message over: its buffer must not be written afterwards (the rows behind the message's own are
+    zeroed as padding, on the side stream, when another rank's message is longer).
+
+    With timing=True (device collectives only) every message gather is bracketed by events on the side stream;
+    `gather_ms` and `gather_bytes_in` (bytes this rank received) accumulate over the retired batches."""
+
+    def __init__(self, group=None, keep_results: bool = True, root=None, payload: str = 'rows', timing: bool = False):
+        if payload not in ('rows', 'header'):
+            raise ValueError("payload must be 'rows' or 'header'")
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.root = root
-        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.rank = dist.get_rank() if self.world > 1 else 0                 # global rank: what `root` and gather's dst name
+        self.grank = dist.get_rank(group) if self.world > 1 else 0           # rank inside the group: the order of gathered data
+        if root is not None and self.world > 1 and root not in dist.get_process_group_ranks(group if group is not None else dist.group.WORLD):
+            raise ValueError(f'root {root} is not a member of the group')
         # RCCL moves device buffers; any other backend (gloo rehearsals) gets the message staged on the host
         self.device_collectives = self.world > 1 and dist.get_backend(group) == 'nccl'
         self.keep_results = keep_results
+        self.payload = payload
+        self.timing = timing
         self.counted = []        # counts exchange issued: (wire, header_rows, counts_host, counts_event, counts_work)
-        self.flying = []         # message gathers issued: (work, out, header_rows, counts, send)
+        self.flying = []         # message gathers issued: (work, out, header_rows, counts, send, events)
         self.results = []        # per batch: (out [world, rows, 6] or list of world [rows, 6], header_rows, counts)
         self.comm = None
         self.host_waits = 0      # times the host found a counts exchange of an earlier batch still unfinished
+        self.gather_ms, self.gather_bytes_in, self.gathers = 0.0, 0, 0
 
     # -- stage 2: the row counts of the batch just submitted
     def _issue_counts(self, wire: torch.Tensor, header_rows: int):
@@ -150,13 +169,16 @@ class RowExchange:
             ev.synchronize()
         counts = [int(c) for c in host.tolist()]
         if self.world == 1:
-            self.flying.append((None, wire[:header_rows + counts[0]].unsqueeze(0), header_rows, counts, None))
+            self.flying.append((None, wire[:header_rows + counts[0]].unsqueeze(0), header_rows, counts, None, None, 0))
             return
         import contextlib
-        n = counts[self.rank]
+        n = counts[self.grank]                     # the gathered counts are in group-rank order
+        if self.payload == 'header':
+            n, counts = 0, [0] * self.world        # nothing behind the header travels
         rows = header_rows + max(max(counts), 0)
         on_device = wire.is_cuda and self.device_collectives
         ctx = torch.cuda.stream(self.comm) if on_device else contextlib.nullcontext()
+        events = None
         with ctx:
             if wire.is_cuda and not on_device:
                 wire = wire[:header_rows + n].cpu()
@@ -167,6 +189,9 @@ class RowExchange:
                 send = torch.zeros((rows, 6), dtype=torch.int32, device=wire.device)
                 send[:header_rows + n] = wire[:header_rows + n]
             send = send.contiguous()
+            if on_device and self.timing:
+                events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                events[0].record(self.comm)
             if self.root is not None:
                 out = None
                 if self.rank == self.root:
@@ -176,8 +201,13 @@ class RowExchange:
                 out = torch.empty((self.world, rows, 6), dtype=torch.int32, device=send.device)
                 work = dist.all_gather_into_tensor(out.view(self.world * rows, 6), send, group=self.group, async_op=True)
             if on_device:
+                if events is not None:
+                    work.wait()                    # orders the side stream behind the collective; the host does not block
+                    events[1].record(self.comm)
+                    work = None
                 wire.record_stream(self.comm)
-        self.flying.append((work, out, header_rows, counts, send))
+        received = 0 if out is None else (self.world - 1) * rows * 24
+        self.flying.append((work, out, header_rows, counts, send, events, received))
         while len(self.flying) > 2:                # retire old gathers (they finished long ago)
             self._retire(self.flying.pop(0))
 
@@ -190,6 +220,12 @@ class RowExchange:
         work, out, header_rows, counts = f[:4]
         if work is not None:
             work.wait()
+        if len(f) > 5:
+            self.gathers += 1
+            self.gather_bytes_in += f[6]
+            if f[5] is not None:
+                f[5][1].synchronize()
+                self.gather_ms += f[5][0].elapsed_time(f[5][1])
         if self.keep_results:
             self.results.append((out, header_rows, counts))
 

@@ -9,10 +9,12 @@ finds every difference between the two results and checks that each one sits on 
   selection   a (class, anchor) selected by one side only must have a reference score within `tol` (relative)
               of conf_thresh or of the k-th largest reference score of its class;
   keep lists  compared as lists of (class, anchor).  At the first rank where they differ the two entries must
-              be explained by (a) a selection difference, (b) a near-tie of the two scores, or (c) an entry
-              kept by one side only whose decisive IoU (against a box kept earlier in its class) is within
-              `iou_tol` of the threshold, or whose score nearly ties with a box it overlaps above the
-              threshold.  What follows the first divergence of an image may cascade and is only counted.
+              be explained by (a) a selection difference of that very candidate, (b) a near-tie of the two
+              scores, or (c) an entry kept by one side only whose IoU against a box that the OTHER side kept
+              earlier in its class is within `iou_tol` of the threshold, whose score nearly ties with such a box
+              that it overlaps above the threshold, or which overlaps, above the threshold, a candidate of its class
+              that only one side selected.  What follows the first divergence of an image may cascade and is only
+              counted.
 
 Test infrastructure only (CPU, torch); nothing in the package imports it.
 """
@@ -108,18 +110,30 @@ def compare_image(ref_scores, hip_scores, ref, hip, class_begin, conf_thresh, to
             so = info(other)[1]
             if abs(s - so) <= tol * max(abs(s), abs(so)):
                 return 'near-tie of two kept scores'
-        # kept by one side only: the decisive IoU against the boxes of its class, or a near-tie with a box it overlaps
+        # Kept by one side only.  On the side that dropped it, the decisive IoU is the one against a box of its class that
+        # this side kept EARLIER (score at least as high): that IoU must sit on the threshold, or the two scores must
+        # nearly tie (then the other side processed them in the other order) with the boxes overlapping above it.
         c = key // P
-        same = torch.nonzero((kr // P) == c).flatten()
-        boxes, scores = ref['boxes'][same], ref['scores'][same]
-        iou = iou_one_to_many(box, boxes)
-        others = kr[same] != key
-        if bool((((iou - iou_thresh).abs() <= iou_tol) & others).any()):
-            return 'IoU within %g of the threshold' % iou_tol
-        if bool((((scores - s).abs() <= tol * max(abs(s), 1e-30)) & (iou > iou_thresh - iou_tol) & others).any()):
-            return 'near-tie with an overlapping box'
-        if any((int(k) in only_one_side) for k in kr[same].tolist()) or any((k // P) == c for k in only_one_side):
-            return 'selection difference in the same class'
+        for keys, kept, side in ((kr, set_r, ref), (kh, set_h, hip)):
+            if key in kept:
+                continue
+            same = torch.nonzero((keys // P) == c).flatten()
+            earlier = [int(i) for i in same.tolist() if int(keys[i]) in kept and int(keys[i]) != key]
+            if not earlier:
+                continue
+            earlier = torch.tensor(earlier)
+            sc = side['scores'][earlier]
+            iou = iou_one_to_many(box, side['boxes'][earlier])
+            near = (sc - s).abs() <= tol * max(abs(s), 1e-30)
+            if bool((((iou - iou_thresh).abs() <= iou_tol) & ((sc >= s) | near)).any()):
+                return 'IoU within %g of the threshold against a box kept earlier' % iou_tol
+            if bool((near & (iou > iou_thresh - iou_tol)).any()):
+                return 'near-tie with an overlapping kept box'
+        # a candidate that only one side selected, in this class and overlapping this box above the threshold
+        for k in only_one_side:
+            if k // P == c and k != key:
+                if float(iou_one_to_many(box, info(k)[0][None, :])[0]) > iou_thresh - iou_tol:
+                    return 'selection difference of an overlapping box'
         return None
 
     ea, eb = explained(a, b), explained(b, a)

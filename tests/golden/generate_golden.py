@@ -353,7 +353,14 @@ def main():
     predict_case('retinanet800', lambda: ret800.pre_predict((locs.clone(), confs.clone()), top_k=1000),
                  H['retinanet800_pboxes'], spec, metas1, out, torch.softmax(confs, -1), 1, 0.01, 1000, big=True)
 
-    # YoloV3.pre_predict has no runnable reference behaviour
+    # SSD512 (24564 default boxes; pre_predict inherited from SSD300): hashes + subsample
+    locs, confs, _ = head_outputs(2006, 2, 24564, 21, sparse_images=(1,))
+    spec = dict(family='ssd512', B=2, C=21, seed=2006, sparse_images=[1], bg_bias=8.0, conf_thresh=0.01, top_k=200,
+                inputs_sha256=[sha(locs), sha(confs)])
+    predict_case('ssd512', lambda: ssd512.pre_predict((locs.clone(), confs.clone())),
+                 H['ssd512_dboxes'], spec, metas2, out, torch.softmax(confs, -1), 1, 0.01, 200, big=True)
+
+    # YoloV3.pre_predict has no runnable reference behaviour as written ...
     locs, confs, objs = head_outputs(2003, 1, 10647, 20, extra=True, yolo=True)
     try:
         yolo.pre_predict((locs.clone(), objs.clone(), confs.clone()))
@@ -361,10 +368,36 @@ def main():
     except TypeError as e:
         manifest['notes']['yolov3_pre_predict'] = f'TypeError: {e}'
 
+    # ... but everything in it except the one call at yolov3.py:320 does run: the in-place sigmoid of x, y, the
+    # sigmoid(cls) * sigmoid(obj) score, the loop over ALL C columns with class id c + 1, the selection rule, the
+    # xywh -> xyxy conversion.  With that one call repaired -- `_calc_coord` handed the 5-column prior rows splits
+    # them into the prior box and its grid length, which is what its signature asks for -- the reference's own
+    # pre_predict and _calc_coord arithmetic produce this fixture.  Only the argument split is this build's reading.
+    class YoloV3Repaired(YoloV3):
+        def _calc_coord(self, locs, pboxes, grid_length=None, *a, **kw):
+            if grid_length is None:
+                pboxes, grid_length = pboxes[:, :4], pboxes[:, 4:]
+            return YoloV3._calc_coord(self, locs, pboxes, grid_length, *a, **kw)
+
+    yolo_fixed = bare(YoloV3Repaired, 20); yolo_fixed.pboxes = yolo_fixed._get_prior_boxes()
+    locs, confs, objs = head_outputs(2007, 2, 10647, 20, sparse_images=(1,), extra=True, yolo=True, obj_bias=-8.0)
+    spec = dict(family='yolov3', B=2, C=20, seed=2007, sparse_images=[1], obj_bias=-8.0, bg_bias=8.0, conf_thresh=0.01, top_k=200,
+                inputs_sha256=[sha(locs), sha(confs), sha(objs)])
+    act = confs.sigmoid() * objs.sigmoid()[..., None]
+    locs_in = locs.clone()
+    predict_case('yolov3', lambda: yolo_fixed.pre_predict((locs_in, objs.clone(), confs.clone())),
+                 H['yolov3_pboxes'], spec, metas2, out, act, 0, 0.01, 200)
+    if only is None or 'predict_yolov3' in only:
+        assert torch.equal(locs_in[..., :2], locs[..., :2].sigmoid()) and torch.equal(locs_in[..., 2:], locs[..., 2:])
+        manifest['notes']['yolov3_pre_predict_fixture'] = (
+            'predict_yolov3.npz: the reference pre_predict with _calc_coord(locs, pboxes[:, :4], pboxes[:, 4:]) '
+            'substituted for the call at yolov3.py:320; the input locs were overwritten in place as at :297')
+
     if only is not None:
         with open(os.path.join(HERE, 'manifest.json')) as f:
             old = json.load(f)
         old['cases'].update(out)
+        old['notes'].update(manifest['notes'])
         manifest, out = old, old['cases']
     manifest['cases'] = out
     with open(os.path.join(HERE, 'manifest.json'), 'w') as f:

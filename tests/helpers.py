@@ -50,7 +50,8 @@ def predict_inputs(z, P):
     if 'out_locs' in z.files:
         return spec, torch.from_numpy(z['out_locs']), torch.from_numpy(z['out_confs']), None
     locs, confs, ext = head_outputs(spec['seed'], spec['B'], P, spec['C'], tuple(spec['sparse_images']),
-                                    extra=spec['family'] in ('fcos',), bg_bias=spec['bg_bias'],
+                                    extra=spec['family'] in ('fcos', 'yolov3'), bg_bias=spec['bg_bias'],
+                                    obj_bias=spec.get('obj_bias', -6.0), yolo=spec['family'] == 'yolov3',
                                     loc_bias=spec.get('loc_bias', 0.0))
     hashes = [sha(locs), sha(confs)] + ([sha(ext)] if ext is not None else [])
     assert hashes == spec['inputs_sha256'], 'seeded inputs differ from the ones the fixture was generated with'

@@ -56,3 +56,32 @@ def test_launcher_environment_means_no_spawn():
     main = src[src.index('def main():'):]
     assert main.index('spawn_ranks(') < main.index('torch.cuda.set_device')
     assert "'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ" in main
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_ranks_rehearsal_on_one_gpu():
+    """The rank body of bench.py for N = 2 as fresh processes on a one-GPU box: `gloo` stands in for RCCL (messages are
+    staged through the host), everything else -- sharding by image, the pipelined count / message exchange, the barrier
+    and max-over-ranks timing, rank 0's line -- is the code the multi-GPU run executes."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env['DETBOX_BENCH_BACKEND'] = 'gloo'
+    for extra, want in ((['--exchange', 'all'], 'all-gather'), (['--exchange', 'root', '--exchange-payload', 'header'], 'gather to rank 0')):
+        r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--blocks', '1',
+                            '--workload', 'ssd300', '--no-extra', '--no-cpu-baseline'] + extra,
+                           capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip().startswith('{')]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        assert d['n_gpus'] == 2 and d['steps'] == 2 and d['scaling'] == 'weak' and d['value'] > 0
+        assert d['config']['global_batch'] == 2 * d['config']['images_per_gpu']
+        assert d['config']['exchange'] == want and d['config']['exchange_host_waits'] is not None
+        ex = d['exchange']
+        assert ex['collective'] == want and ex['batches_measured'] >= 2
+        if 'header' in extra:
+            assert ex['payload'] == 'header' and ex['bytes_in_per_step_per_rank'] < 24 * 64     # headers only: a few rows
+        else:
+            assert ex['payload'] == 'rows' and ex['bytes_in_per_step_per_rank'] > 24 * d['config']['kept_per_image']

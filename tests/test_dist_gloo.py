@@ -137,3 +137,81 @@ def test_row_exchange_pipelined(world, root):
             want_ids, want_vals = rows_from_detections([_fake_dets(i) for i in imgs], [(1 << 33) + i for i in imgs],
                                                        [(100 + i, 200 + i) for i in imgs])
             assert torch.equal(torch.from_numpy(gids), want_ids) and torch.equal(torch.from_numpy(gvals), want_vals)
+
+
+def _subgroup_worker(rank, world, port, members, batches, per_rank, q, root, payload):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    group = dist.new_group(ranks=members)            # every rank of the world takes part in creating it
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import wire_from_rows
+    from object_detection_amd.dist import RowExchange, unpack_gathered
+    out = []
+    if rank in members:
+        hdr = (2 + (per_rank + 1) + 4 * per_rank + 5) // 6
+        ex = RowExchange(group=group, root=root, payload=payload)
+        assert ex.world == len(members) and ex.rank == rank and ex.grank == members.index(rank)
+        for k in range(batches):
+            imgs = _images_of(k, rank, world, per_rank)
+            dets = [_fake_dets(i) for i in imgs]
+            wire = wire_from_rows(dets, [(1 << 33) + i for i in imgs], [(100 + i, 200 + i) for i in imgs], hdr)
+            ex.submit(wire, per_rank, hdr)
+        for bt in ex.finish():
+            if bt[0] is None:
+                continue
+            if payload == 'header':                  # only the headers travelled: row counts per image of every member
+                out.append([[int(x) for x in bt[0][r].reshape(-1)[2:2 + int(bt[0][r].reshape(-1)[1]) + 1]] for r in range(len(bt[0]))])
+            else:
+                a, b = unpack_gathered(bt)
+                out.append((a.numpy(), b.numpy()))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('root,payload', [(None, 'rows'), (3, 'rows'), (None, 'header')])
+def test_row_exchange_in_a_sub_group(root, payload):
+    """A group that is not the whole world (global ranks 1 and 3 of four): the gathered counts come in GROUP-rank
+    order, `root` names a GLOBAL rank.  Rank 1 is one image short in batch 1, so the two messages differ in length."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import rows_from_detections
+    world, members, batches, per_rank = 4, [1, 3], 4, 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, world, port, members, batches, per_rank, q, root, payload))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == [] and got[2] == []
+    for rank_ in members:
+        per_batch = got[rank_]
+        if root is not None and rank_ != root:
+            assert per_batch == []
+            continue
+        assert len(per_batch) == batches
+        for k, item in enumerate(per_batch):
+            per_member = [[_fake_dets(i) for i in _images_of(k, r, world, per_rank)] for r in members]
+            if payload == 'header':
+                for offs, dets in zip(item, per_member):
+                    want = [0]
+                    for d in dets:
+                        want.append(want[-1] + int(d[0].numel()))
+                    assert offs == want
+                continue
+            imgs = [i for r in members for i in _images_of(k, r, world, per_rank)]
+            want_ids, want_vals = rows_from_detections([_fake_dets(i) for i in imgs], [(1 << 33) + i for i in imgs],
+                                                       [(100 + i, 200 + i) for i in imgs])
+            assert torch.equal(torch.from_numpy(item[0]), want_ids) and torch.equal(torch.from_numpy(item[1]), want_vals)
+
+
+def test_row_exchange_rejects_an_unknown_payload():
+    from object_detection_amd.dist import RowExchange
+    with pytest.raises(ValueError):
+        RowExchange(payload='boxes')

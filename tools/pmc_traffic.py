@@ -15,6 +15,17 @@ import os
 import re
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from object_detection_amd.build import source_hash  # noqa: E402
+
+
+def recorded_hash(pass_dir):
+    """The hash tools/profile_round.sh left next to the pass directories, else the hash of the sources as they are now."""
+    f = os.path.join(os.path.dirname(os.path.abspath(pass_dir.rstrip('/'))), 'source_sha256.txt')
+    if os.path.exists(f):
+        return open(f).read().strip()
+    return source_hash()
+
 WIDE_READERS = {'select_scan', 'select_sample', 'score_hist', 'select_emit', 'activate_scores', 'stream_read'}
 PAT = re.compile(r'(select_[a-z]+|nms_[a-z]+|score_hist|activate_scores|assign_[a-z]+|pack_detections|stream_read)')
 
@@ -49,10 +60,13 @@ def main():
             allt = json.load(fh)
     except (OSError, ValueError):
         allt = {}
+    out['_source_sha256'] = recorded_hash(sys.argv[1])          # the kernels these counters were taken on
     allt[key] = out
     with open(path, 'w') as fh:
         json.dump(allt, fh, indent=1, sort_keys=True)
     for k, v in out.items():
+        if k.startswith('_'):
+            continue
         print(k, round(v['hbm_bytes_per_launch'] / 1e6, 2), 'MB/launch')
 
 

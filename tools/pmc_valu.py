@@ -13,6 +13,17 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from object_detection_amd.build import source_hash  # noqa: E402
+
+
+def recorded_hash(pass_dir):
+    """The hash tools/profile_round.sh left next to the pass directories, else the hash of the sources as they are now."""
+    f = os.path.join(os.path.dirname(os.path.abspath(pass_dir.rstrip('/'))), 'source_sha256.txt')
+    if os.path.exists(f):
+        return open(f).read().strip()
+    return source_hash()
+
 
 def main():
     d, key = sys.argv[1:3]
@@ -35,6 +46,7 @@ def main():
             allv = json.load(fh)
     except (OSError, ValueError):
         allv = {}
+    out['source_sha256'] = recorded_hash(sys.argv[1])           # the kernels these counters were taken on
     allv.setdefault(key, {})['nms_segments'] = out
     with open(path, 'w') as fh:
         json.dump(allv, fh, indent=1, sort_keys=True)

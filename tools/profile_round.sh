@@ -8,6 +8,8 @@ TAG=${1:-prof}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
+# the kernel sources the counters below are taken on (tools/pmc_*.py stamp profiles/*.json with it)
+python3 -c "import sys; sys.path.insert(0, '$ROOT'); from object_detection_amd.build import source_hash; print(source_hash())" > "$OUT/source_sha256.txt"
 cd /tmp && export TMPDIR=/tmp
 B="python3 $ROOT/bench.py --no-cpu-baseline --no-extra"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- $B > "$OUT/stats.log" 2>&1
