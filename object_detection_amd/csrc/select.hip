@@ -263,7 +263,7 @@ __device__ inline void for_each_subtile(const float *__restrict__ in, const floa
                                                     g.shift, x, ctx);
         f(x, valid, r0, ctx);
         __syncthreads();          // sub-tile s consumed by every wave, DMA of the next one landed
-        after(s);
+        after(s);                 // (behind the next sub-tile's DMA issue instead, the scan's hand-over costs 12 us more)
         g = gn;
         buf ^= 1;
     }
@@ -567,7 +567,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
                                                                  uint32_t *__restrict__ gcnt,
                                                                  unsigned long long *__restrict__ staging) {
     extern __shared__ float s_dynf[];
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    // The workgroups of an image share an XCD: their partial writes to the image's staging lists meet in one L2 (and fill
+    // whole lines there before they leave it), the per-class counters live in that L2, and select_finalize, mapped the
+    // same way, finds the lists where they were written.
+    const TileOfImage wg = xcd_affine_tile();
+    const int b = wg.y, tid = threadIdx.x, lane = tid & 63;
     const int Cs = sp.Cs, cb = sp.cb, C = sp.C;
     const uint32_t key_thr = sp.key_thr;
     const SelRule *rb = rules + (size_t)b * Cs;
@@ -647,7 +651,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
     // Workgroup j of an image takes sub-tiles j, j + gx, j + 2 gx, ...: at any moment the workgroups of an image read
     // one compact window of it (3 % faster than a contiguous run per workgroup).
     for_each_subtile<ACT, EPT>(
-        in, extra, b, sp.P, C, sp.total_floats, (long long)blockIdx.x, (long long)sp.n_sub, (long long)gridDim.x, s_dynf, sp.tile_floats,
+        in, extra, b, sp.P, C, sp.total_floats, (long long)wg.x, (long long)sp.n_sub, (long long)gridDim.x, s_dynf, sp.tile_floats,
         [&](float (&x)[EPT], bool valid, int r0, const RowCtx &ctx) {
             // bit i: element i is staged.  Built high element first with compare-into-VCC + add-with-carry
             // (pm = 2 * pm + (x >= t)): two VALU per element, no select chains
