@@ -212,7 +212,7 @@ def measured_traffic(workload, regime, kernel):
 
 
 KERNELS = ['assign_anchor', 'assign_fixup', 'assign_fcos', 'select_sample', 'select_plan', 'select_scan',
-           'select_check', 'select_fallback', 'select_materialize', 'score_hist', 'select_kth',
+           'select_check', 'select_fallback', 'score_hist', 'select_kth',
            'select_refine', 'select_emit', 'select_finalize', 'select_direct_stats', 'select_direct', 'nms_segments', 'nms_scan', 'nms_merge',
            'nms_split', 'nms_tile', 'pack_detections']
 PRICED = ('select_scan', 'score_hist', 'select_emit', 'assign_anchor', 'assign_fcos', 'nms_segments', 'select_finalize',

@@ -95,7 +95,10 @@ int detbox_assign_anchor(int mode, const float *anchors, int64_t P,
  * held until the process ends).  total_gt beyond DETBOX_ASSIGN_NOALLOC_MAX_GT returns DETBOX_ERR_UNSUPPORTED.
  * The call makes no hipMalloc / hipFree; the device that `stream` belongs to must be current.  All calls on one
  * GPU share that GPU's array: calls that overlap there (two streams, two threads) race; order them on one
- * stream or use detbox_assign_anchor with separate workspaces. */
+ * stream or use detbox_assign_anchor with separate workspaces.
+ * Graph capture: the first call on a device looks the array's address up (hipGetSymbolAddress), which is set-up work,
+ * not a stream operation.  Make one ordinary call per device (any small input) before capturing; from then on the
+ * entry point issues a memset and kernel launches on `stream` and nothing else, and can be captured and replayed. */
 #define DETBOX_ASSIGN_NOALLOC_MAX_GT 65536
 int detbox_assign_anchor_noalloc(int mode, const float *anchors, int64_t P,
                                  const float *gt_boxes, const int64_t *gt_labels, const int32_t *gt_offsets,
@@ -175,8 +178,10 @@ int detbox_activate_scores(int activation, const float *in, const float *extra, 
  *                 (= c + class_id_offset)
  *   out_seg_offsets [B, (C-class_begin)+1]: class segment boundaries inside image b's rows
  *   out_counts    [B]
- * Limits: 1 <= top_k <= DETBOX_MAX_TOP_K, C <= 256, C - class_begin <= 128.  With a fused activation
- * the workspace also reserves B*P*C floats that only the exact fallback path touches. */
+ * Limits: 1 <= top_k <= DETBOX_MAX_TOP_K, C <= 256, C - class_begin <= 128.  The workspace holds
+ * the staging lists, the samples and the histograms; no copy of the activated scores is kept (the exact path, taken
+ * when the sampled guess fails or P < 4096, recomputes them from the head output), so its size does not depend on
+ * `activation`. */
 size_t detbox_select_decode_workspace_bytes(int64_t B, int64_t P, int64_t C, int class_begin, int top_k,
                                             int activation);
 int detbox_select_decode(int decode_mode, int activation, const float *scores, const float *extra,
@@ -268,7 +273,7 @@ int detbox_pack_detections_wire(const float *boxes, const float *scores, const i
  * detbox_profile_read synchronises those events and returns the accumulated time and launch
  * count of the kernel called `name`; reset drops all samples.  Kernel names: "box_convert",
  * "box_iou", "assign_anchor", "assign_fixup", "assign_fcos", "activate_scores", "select_sample",
- * "select_plan", "select_scan", "select_check", "select_materialize", "score_hist", "select_kth",
+ * "select_plan", "select_scan", "select_check", "score_hist", "select_kth",
  * "select_refine", "select_emit", "select_finalize", "select_direct_stats", "select_direct", "nms_segments", "nms_scan", "nms_merge",
  * "nms_split", "nms_tile", "pack_detections", "pack_wire", "topk_mask", "focal_forward", "focal_backward",
  * "smooth_l1_forward", "smooth_l1_backward". */

@@ -22,9 +22,9 @@
 // The focal-loss kernels at the end of the file stream the same tensor through the same
 // sub-tile machinery (training side).
 // Fallback (kernels exit at once unless the flag is up; also the only path for tiny P):
-//   select_materialize (fused activation only) writes the activated scores to the workspace,
 //   score_hist / select_kth / select_refine / select_emit find the exact boundary bin (or, on
-//   massive ties, the exact 64-bit cut-off key) from a full histogram and re-stage.
+//   massive ties, the exact 64-bit cut-off key) from a full histogram and re-stage; with a fused
+//   activation they recompute the scores from the head output (no copy of the scores is kept).
 //
 // Selection key: K = ((okey(score) - okey(thr)) << 32) | (0xffffffff - anchor): larger K
 // means higher score, then lower anchor index (boundary ties go to the lower anchor), and
@@ -960,6 +960,208 @@ __global__ __launch_bounds__(PASS_BLOCK) void select_emit_kernel(const float *__
     });
 }
 
+// The same three passes when the activation is fused: the scores are not in memory, so every pass streams the head
+// output through the scan's sub-tile pipeline and recomputes them -- with the scan's own arithmetic, bit for bit, which
+// is what makes the counts of the passes agree with one another and with the scan's staged keys.
+
+// lds_hist: the per-class counters are packed 16-bit pairs in LDS behind the two sub-tile buffers (a workgroup sees
+// fewer than 65536 anchors); otherwise (very wide heads: the counters do not fit beside the sub-tiles) they are
+// added to the global histogram directly.
+template <int ACT, int EPT>
+__global__ __launch_bounds__(SCAN_BLOCK) void score_hist_fused_kernel(const float *__restrict__ in,
+                                                                      const float *__restrict__ extra, SelParams sp,
+                                                                      const SelRule *__restrict__ rules,
+                                                                      const uint32_t *__restrict__ flag,
+                                                                      uint32_t *__restrict__ ghist, int lds_hist) {
+    extern __shared__ float s_dynf[];
+    __shared__ uint32_t s_pending[MAX_SEL_CLASSES];
+    if (*flag == 0u) return;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int Cs = sp.Cs, cb = sp.cb, C = sp.C;
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_dynf + 2 * (size_t)sp.tile_floats);
+    const int words = lds_hist ? Cs * (NB / 2) : 0;
+    for (int i = tid; i < words; i += SCAN_BLOCK) s_hist[i] = 0u;
+    for (int i = tid; i < Cs; i += SCAN_BLOCK) s_pending[i] = rules[(size_t)b * Cs + i].mode == RULE_PENDING ? 1u : 0u;
+    __syncthreads();
+    uint32_t *gh = ghist + (size_t)b * Cs * NB;
+    const int sub = tid % LPR;
+    const float thr = sp.thr;
+    const uint32_t key_thr = sp.key_thr;
+    const int shift = sp.shift;
+    for_each_subtile<ACT, EPT>(
+        in, extra, b, sp.P, C, sp.total_floats, (long long)blockIdx.x, (long long)sp.n_sub, (long long)gridDim.x, s_dynf, sp.tile_floats,
+        [&](float (&x)[EPT], bool valid, int, const RowCtx &) {
+            if (!valid) return;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                const int c = sub + LPR * i;
+                if (c >= cb && c < C && x[i] > thr && s_pending[c - cb]) {
+                    const uint32_t bin = bin_of(okey(x[i]) - key_thr, shift);
+                    if (lds_hist) atomicAdd(&s_hist[(c - cb) * (NB / 2) + (bin >> 1)], 1u << ((bin & 1u) * 16u));
+                    else atomicAdd(&gh[(size_t)(c - cb) * NB + bin], 1u);
+                }
+            }
+        },
+        [](long long) {});
+    __syncthreads();
+    for (int i = tid; i < words; i += SCAN_BLOCK) {
+        const uint32_t v = s_hist[i];
+        if (v) {
+            const uint32_t lo = v & 0xffffu, hi = v >> 16;
+            if (lo) atomicAdd(&gh[2 * i], lo);
+            if (hi) atomicAdd(&gh[2 * i + 1], hi);
+        }
+    }
+}
+
+// Exact cut-off keys of the image's RULE_EXACT pairs: one workgroup per image streams the image once per 8 key bits
+// and narrows the key interval of up to `group` pairs at a time (256 LDS counters each, behind the sub-tile buffers).
+// Only massive ties at the boundary bring a pair here; one workgroup per image needs no synchronisation between the
+// rounds, which is what keeps this a single launch.
+template <int ACT, int EPT>
+__global__ __launch_bounds__(SCAN_BLOCK) void select_refine_fused_kernel(const float *__restrict__ in,
+                                                                         const float *__restrict__ extra, SelParams sp,
+                                                                         SelRule *__restrict__ rules,
+                                                                         const uint32_t *__restrict__ flag, int group) {
+    extern __shared__ float s_dynf[];
+    __shared__ unsigned long long s_lo[MAX_SEL_CLASSES], s_hi[MAX_SEL_CLASSES];
+    __shared__ uint32_t s_need[MAX_SEL_CLASSES];
+    __shared__ int s_sh[MAX_SEL_CLASSES], s_slot[MAX_SEL_CLASSES], s_cls[MAX_SEL_CLASSES];
+    __shared__ int s_n, s_active;
+    if (*flag == 0u) return;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int Cs = sp.Cs, cb = sp.cb, C = sp.C;
+    SelRule *rb = rules + (size_t)b * Cs;
+    if (tid == 0) {
+        int n = 0;
+        for (int ci = 0; ci < Cs; ++ci)
+            if (rb[ci].mode == RULE_EXACT) s_cls[n++] = ci;
+        s_n = n;
+    }
+    __syncthreads();
+    const int n_exact = s_n;
+    if (n_exact == 0) return;
+    uint32_t *s_h = reinterpret_cast<uint32_t *>(s_dynf + 2 * (size_t)sp.tile_floats);
+    const int r = tid / LPR, sub = tid % LPR;
+    const float thr = sp.thr;
+    const uint32_t key_thr = sp.key_thr;
+    for (int g0 = 0; g0 < n_exact; g0 += group) {
+        const int gn = min(group, n_exact - g0);
+        for (int i = tid; i < Cs; i += SCAN_BLOCK) s_slot[i] = -1;
+        __syncthreads();
+        if (tid < gn) {
+            const int ci = s_cls[g0 + tid];
+            s_slot[ci] = tid;
+            const uint32_t beta = rb[ci].beta;
+            s_lo[tid] = (unsigned long long)beta << (sp.shift + 32);
+            s_hi[tid] = (beta == (uint32_t)(NB - 1)) ? ~0ull : ((((unsigned long long)beta + 1ull) << (sp.shift + 32)) - 1ull);
+            s_need[tid] = (uint32_t)sp.top_k - rb[ci].n_above;
+        }
+        __syncthreads();
+        for (int iter = 0; iter < 16; ++iter) {            // 64 key bits / 8 per round, with slack
+            if (tid == 0) s_active = 0;
+            __syncthreads();
+            if (tid < gn) {
+                const unsigned long long lo = s_lo[tid], hi = s_hi[tid];
+                int sh = -1;
+                if (lo < hi) {
+                    const int sb = 64 - __clzll((long long)(hi - lo));
+                    sh = sb > 8 ? sb - 8 : 0;
+                    s_active = 1;
+                }
+                s_sh[tid] = sh;
+            }
+            for (int i = tid; i < gn * 256; i += SCAN_BLOCK) s_h[i] = 0u;
+            __syncthreads();
+            if (!s_active) break;
+            for_each_subtile<ACT, EPT>(
+                in, extra, b, sp.P, C, sp.total_floats, 0ll, (long long)sp.n_sub, 1ll, s_dynf, sp.tile_floats,
+                [&](float (&x)[EPT], bool valid, int r0, const RowCtx &) {
+                    if (!valid) return;
+#pragma unroll
+                    for (int i = 0; i < EPT; ++i) {
+                        const int c = sub + LPR * i;
+                        if (c >= cb && c < C && x[i] > thr) {
+                            const int slot = s_slot[c - cb];
+                            if (slot >= 0 && s_sh[slot] >= 0) {
+                                const unsigned long long K = make_key(x[i], key_thr, (uint32_t)(r0 + r));
+                                const unsigned long long lo = s_lo[slot];
+                                if (K >= lo && K <= s_hi[slot]) atomicAdd(&s_h[slot * 256 + (int)((K - lo) >> s_sh[slot])], 1u);
+                            }
+                        }
+                    }
+                },
+                [](long long) {});
+            __syncthreads();
+            if (tid < gn && s_sh[tid] >= 0) {
+                const uint32_t *h = s_h + tid * 256;
+                const unsigned long long lo = s_lo[tid], hi = s_hi[tid];
+                const int sh = s_sh[tid];
+                const uint32_t need = s_need[tid];
+                uint32_t acc = 0;
+                int sbin = 0;
+                for (int i = 255; i >= 0; --i) {
+                    if (acc + h[i] >= need) { sbin = i; break; }
+                    acc += h[i];
+                }
+                const unsigned long long nlo = lo + ((unsigned long long)sbin << sh);
+                unsigned long long nhi = nlo + ((1ull << sh) - 1ull);
+                if (nhi > hi || nhi < nlo) nhi = hi;
+                s_lo[tid] = nlo; s_hi[tid] = nhi; s_need[tid] = need - acc;
+            }
+            __syncthreads();
+        }
+        if (tid < gn) {
+            SelRule *rp = rb + s_cls[g0 + tid];
+            rp->cutoff = s_lo[tid];
+            rp->min_score = score_from_d(key_thr, s_lo[tid] >> 32);
+        }
+        __syncthreads();
+    }
+}
+
+template <int ACT, int EPT>
+__global__ __launch_bounds__(SCAN_BLOCK) void select_emit_fused_kernel(const float *__restrict__ in,
+                                                                       const float *__restrict__ extra, SelParams sp,
+                                                                       const SelRule *__restrict__ rules,
+                                                                       const uint32_t *__restrict__ flag,
+                                                                       uint32_t *__restrict__ cnt,
+                                                                       unsigned long long *__restrict__ staging) {
+    extern __shared__ float s_dynf[];
+    __shared__ float s_min[MAX_SEL_CLASSES];
+    if (*flag == 0u) return;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int Cs = sp.Cs, cb = sp.cb, C = sp.C, shift = sp.shift, cap = sp.cap;
+    const SelRule *rb = rules + (size_t)b * Cs;
+    for (int i = tid; i < Cs; i += SCAN_BLOCK)
+        s_min[i] = (rb[i].mode != RULE_STAGED && rb[i].n_sel) ? rb[i].min_score : __builtin_inff();
+    __syncthreads();
+    const int r = tid / LPR, sub = tid % LPR;
+    const uint32_t key_thr = sp.key_thr;
+    for_each_subtile<ACT, EPT>(
+        in, extra, b, sp.P, C, sp.total_floats, (long long)blockIdx.x, (long long)sp.n_sub, (long long)gridDim.x, s_dynf, sp.tile_floats,
+        [&](float (&x)[EPT], bool valid, int r0, const RowCtx &) {
+            if (!valid) return;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                const int c = sub + LPR * i;
+                if (c >= cb && c < C && x[i] >= s_min[c - cb]) {
+                    const int ci = c - cb;
+                    const unsigned long long K = make_key(x[i], key_thr, (uint32_t)(r0 + r));
+                    const SelRule rl = rb[ci];
+                    bool take = true;
+                    if (rl.mode == RULE_HIST) take = bin_of((uint32_t)(K >> 32), shift) >= rl.beta;
+                    else if (rl.mode == RULE_EXACT) take = K >= rl.cutoff;
+                    if (take) {
+                        const uint32_t slot = atomicAdd(&cnt[(size_t)b * Cs + ci], 1u);
+                        if (slot < (uint32_t)cap) staging[((size_t)b * Cs + ci) * cap + slot] = K;
+                    }
+                }
+            }
+        },
+        [](long long) {});
+}
+
 // ---------------------------------------------------------------------------------------------
 // Finalize: exact top-k of the staged keys, anchor order, decode
 // ---------------------------------------------------------------------------------------------
@@ -1539,7 +1741,7 @@ SelPlan make_plan(int64_t B, int64_t P, int64_t C, int64_t Cs, int top_k) {
     return sp;
 }
 
-struct SelLayout { size_t hist, cnt, flag, img_ovf, rules, staging, samp, scores, total; };
+struct SelLayout { size_t hist, cnt, flag, img_ovf, rules, staging, samp, total; };
 
 bool use_direct(int64_t B, int64_t P, int64_t C) { return P <= DIRECT_MAX_P && B * P * C <= DIRECT_MAX_SCORES; }
 
@@ -1548,7 +1750,7 @@ size_t direct_bytes(int64_t B, int64_t P, int64_t Cs) {
     return align_up((size_t)B * Cs * P * sizeof(float), 256) + align_up((size_t)B * Cs * sizeof(uint32_t), 256);
 }
 
-SelLayout layout(int64_t B, int64_t P, int64_t C, int64_t Cs, const SelPlan &pl, int act) {
+SelLayout layout(int64_t B, int64_t P, int64_t C, int64_t Cs, const SelPlan &pl) {
     SelLayout L;
     size_t off = 0;
     if (use_direct(B, P, C)) {
@@ -1563,9 +1765,7 @@ SelLayout layout(int64_t B, int64_t P, int64_t C, int64_t Cs, const SelPlan &pl,
     L.rules = off; off = align_up(off + (size_t)B * Cs * sizeof(SelRule), 256);
     L.staging = off; off = align_up(off + (size_t)B * Cs * pl.cap * sizeof(unsigned long long), 256);
     L.samp = off; off = align_up(off + (size_t)B * Cs * pl.ns_cap * sizeof(float), 256);
-    L.scores = off;
-    if (act != ACT_NONE) off = align_up(off + (size_t)B * P * C * sizeof(float), 256);   // fallback only
-    L.total = off;
+    L.total = off;          // the exact path keeps no copy of the scores: with a fused activation it recomputes them
     return L;
 }
 
@@ -1583,9 +1783,13 @@ struct FastArgs {
     uint32_t *flag, *cnt, *img_ovf, *hist;
     SelRule *rules;
     unsigned long long *staging;
-    float *samp, *scores_ws;
+    float *samp;
+    int32_t *seg_off, *counts;
     hipStream_t s;
 };
+
+// LDS of the exact path's passes when they recompute the scores: two sub-tile buffers, then the pass's own counters.
+constexpr size_t FUSED_LDS_BUDGET = 150 * 1024;
 
 template <int ACT, int EPT>
 struct LaunchFast {
@@ -1629,11 +1833,42 @@ struct LaunchFast {
             DETBOX_LAUNCH_CHECK();
         }
         if (ACT != ACT_NONE) {
-            if (int rc = set_lds(activate_scores_kernel<ACT, EPT>, 2 * tile_bytes)) return rc;
-            ProfScope ps("select_materialize", s);
-            activate_scores_kernel<ACT, EPT><<<dim3(gx, (unsigned)a.B), dim3(SCAN_BLOCK), 2 * tile_bytes, s>>>(
-                a.in, a.extra, sp, a.flag, a.scores_ws);
-            DETBOX_LAUNCH_CHECK();
+            // the exact path on recomputed scores; every launch returns at once unless the flag is up
+            // (a workgroup's packed 16-bit counters hold fewer than 65536 anchors: at most 1023 sub-tiles each)
+            const unsigned gxh = (unsigned)std::max<int64_t>(gx, (sp.n_sub + 1022) / 1023);
+            {
+                const size_t hist_bytes = (size_t)sp.Cs * (NB / 2) * 4;
+                const int lds_hist = 2 * tile_bytes + hist_bytes <= FUSED_LDS_BUDGET ? 1 : 0;
+                const size_t lds = 2 * tile_bytes + (lds_hist ? hist_bytes : 0);
+                if (int rc = set_lds(score_hist_fused_kernel<ACT, EPT>, lds)) return rc;
+                ProfScope ps("score_hist", s);
+                score_hist_fused_kernel<ACT, EPT><<<dim3(gxh, (unsigned)a.B), dim3(SCAN_BLOCK), lds, s>>>(
+                    a.in, a.extra, sp, a.rules, a.flag, a.hist, lds_hist);
+                DETBOX_LAUNCH_CHECK();
+            }
+            {
+                ProfScope ps("select_kth", s);
+                select_kth_kernel<<<dim3((unsigned)a.B), dim3(256), 0, s>>>(a.hist, sp, a.rules, a.seg_off, a.counts);
+                DETBOX_LAUNCH_CHECK();
+            }
+            {
+                int group = (int)((FUSED_LDS_BUDGET - 2 * tile_bytes) / 1024);
+                if (group > sp.Cs) group = sp.Cs;
+                if (group < 1) group = 1;
+                const size_t lds = 2 * tile_bytes + (size_t)group * 1024;
+                if (int rc = set_lds(select_refine_fused_kernel<ACT, EPT>, lds)) return rc;
+                ProfScope ps("select_refine", s);
+                select_refine_fused_kernel<ACT, EPT><<<dim3((unsigned)a.B), dim3(SCAN_BLOCK), lds, s>>>(
+                    a.in, a.extra, sp, a.rules, a.flag, group);
+                DETBOX_LAUNCH_CHECK();
+            }
+            {
+                if (int rc = set_lds(select_emit_fused_kernel<ACT, EPT>, 2 * tile_bytes)) return rc;
+                ProfScope ps("select_emit", s);
+                select_emit_fused_kernel<ACT, EPT><<<dim3(gxh, (unsigned)a.B), dim3(SCAN_BLOCK), 2 * tile_bytes, s>>>(
+                    a.in, a.extra, sp, a.rules, a.flag, a.cnt, a.staging);
+                DETBOX_LAUNCH_CHECK();
+            }
         }
         return DETBOX_OK;
     }
@@ -1735,7 +1970,8 @@ extern "C" int detbox_activate_scores(int activation, const float *in, const flo
 extern "C" size_t detbox_select_decode_workspace_bytes(int64_t B, int64_t P, int64_t C, int class_begin, int top_k,
                                                        int activation) {
     if (B <= 0 || C <= class_begin || top_k <= 0) return 256;
-    return layout(B, P, C, C - class_begin, make_plan(B, P, C, C - class_begin, top_k), activation).total;
+    (void)activation;       // the workspace does not depend on it: no pass keeps a copy of the activated scores
+    return layout(B, P, C, C - class_begin, make_plan(B, P, C, C - class_begin, top_k)).total;
 }
 
 extern "C" int detbox_select_decode(int decode_mode, int activation, const float *scores, const float *extra,
@@ -1777,7 +2013,7 @@ extern "C" int detbox_select_decode(int decode_mode, int activation, const float
     DETBOX_CHECK_ARG(decode_mode != DETBOX_DECODE_FCOS || (uintptr_t)anchors % 8 == 0, "points must be 8-byte aligned");
     const SelPlan plan = make_plan(B, P, C, Cs, top_k);
     const int cap = plan.cap;
-    const SelLayout L = layout(B, P, C, Cs, plan, activation);
+    const SelLayout L = layout(B, P, C, Cs, plan);
     if (!workspace || (uintptr_t)workspace % 256 || workspace_bytes < L.total) {
         set_error("detbox_select_decode: workspace missing, misaligned or smaller than %zu bytes", L.total);
         return DETBOX_ERR_WORKSPACE;
@@ -1790,8 +2026,6 @@ extern "C" int detbox_select_decode(int decode_mode, int activation, const float
     SelRule *rules = reinterpret_cast<SelRule *>(ws + L.rules);
     unsigned long long *staging = reinterpret_cast<unsigned long long *>(ws + L.staging);
     float *samp = reinterpret_cast<float *>(ws + L.samp);
-    float *scores_ws = reinterpret_cast<float *>(ws + L.scores);
-    const float *scores_eff = activation == ACT_NONE ? scores : scores_ws;
 
     SelParams sp;
     std::memset(&sp, 0, sizeof(sp));
@@ -1856,30 +2090,32 @@ extern "C" int detbox_select_decode(int decode_mode, int activation, const float
         FastArgs a;
         a.in = scores; a.extra = extra; a.sp = sp; a.B = B; a.flag = flag; a.cnt = cnt; a.img_ovf = img_ovf; a.hist = ghist;
         a.rules = rules; a.staging = staging; a.samp = samp;
-        a.scores_ws = scores_ws; a.s = s;
+        a.seg_off = out_seg_offsets; a.counts = out_counts; a.s = s;
         if (int rc = dispatch_act_ept<LaunchFast>(activation, ept_for(C), a)) return rc;
     }
-    {
+    if (activation == ACT_NONE) {            // the exact path on the scores as given (fused: launched above, on recomputed scores)
+      {
         ProfScope ps("score_hist", s);
         const size_t lds = (size_t)Cs * (NB / 2) * 4 + (size_t)Cs * 4;
         if (int rc2 = set_lds(score_hist_kernel, lds)) return rc2;
-        score_hist_kernel<<<dim3((unsigned)tiles, (unsigned)B), dim3(PASS_BLOCK), lds, s>>>(scores_eff, sp, rules, flag, ghist);
+        score_hist_kernel<<<dim3((unsigned)tiles, (unsigned)B), dim3(PASS_BLOCK), lds, s>>>(scores, sp, rules, flag, ghist);
         DETBOX_LAUNCH_CHECK();
-    }
-    {
+      }
+      {
         ProfScope ps("select_kth", s);
         select_kth_kernel<<<dim3((unsigned)B), dim3(256), 0, s>>>(ghist, sp, rules, out_seg_offsets, out_counts);
         DETBOX_LAUNCH_CHECK();
-    }
-    {
+      }
+      {
         ProfScope ps("select_refine", s);
-        select_refine_kernel<<<dim3((unsigned)Cs, (unsigned)B), dim3(256), 0, s>>>(scores_eff, sp, rules, flag);
+        select_refine_kernel<<<dim3((unsigned)Cs, (unsigned)B), dim3(256), 0, s>>>(scores, sp, rules, flag);
         DETBOX_LAUNCH_CHECK();
-    }
-    {
+      }
+      {
         ProfScope ps("select_emit", s);
-        select_emit_kernel<<<dim3((unsigned)tiles, (unsigned)B), dim3(PASS_BLOCK), 0, s>>>(scores_eff, sp, rules, flag, cnt, staging);
+        select_emit_kernel<<<dim3((unsigned)tiles, (unsigned)B), dim3(PASS_BLOCK), 0, s>>>(scores, sp, rules, flag, cnt, staging);
         DETBOX_LAUNCH_CHECK();
+      }
     }
     {
         ProfScope ps("select_finalize", s);

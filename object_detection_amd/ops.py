@@ -70,9 +70,10 @@ def _to(t: torch.Tensor, device) -> torch.Tensor:
 _ws_sizes = {}
 
 
-def _ws_bytes(fn, *args) -> int:
-    """Workspace size of an operator for one set of sizes, asked from the library once."""
-    key = (fn.__name__, args)
+def _ws_bytes(device, fn, *args) -> int:
+    """Workspace size of an operator for one set of sizes on one device, asked from the library once (the library may
+    size a workspace by the device's CU count, so the answer of one device is not reused for another)."""
+    key = (device.index, fn.__name__, args)
     n = _ws_sizes.get(key)
     if n is None:
         if len(_ws_sizes) > 4096:
@@ -95,9 +96,10 @@ def _workspace(device, nbytes: int, tag: str, stream: Optional[int] = None) -> t
 
 def release_workspaces(device=None) -> int:
     """Drops the cached scratch buffers (all of them, or those of one device) and returns how many bytes they held.
-    The buffers are grow-only per (device, operator, stream): after a sweep over very large batches -- the selection
-    reserves 4*B*P*C bytes for its exact fall-back when the activation is fused -- this hands the memory back to the
-    caching allocator.  Only call it when no operator is in flight on the streams concerned."""
+    The buffers are grow-only per (device, operator, stream): after a sweep over very large batches this hands the memory
+    (staging lists and kept runs that grow with the batch) back to the caching allocator.  Only call it when no operator is in flight on the streams concerned.  A captured HIP graph
+    holds the ADDRESSES of the buffers its launches were given: releasing (or outgrowing) a buffer a graph was captured
+    with leaves that graph pointing at freed memory, so destroy such graphs first and capture them again afterwards."""
     index = None if device is None else torch.device(device).index
     freed = 0
     for key in [k for k in _workspaces if index is None or k[0] == index]:
@@ -222,7 +224,7 @@ def assign_anchor(anchors: torch.Tensor, gt_boxes: torch.Tensor, gt_labels: torc
     L = _lib.lib()
     with _on(dev):
         st = _stream(dev)
-        ws = _workspace(dev, _ws_bytes(L.detbox_assign_anchor_workspace_bytes, total_gt), 'assign', st)
+        ws = _workspace(dev, _ws_bytes(dev, L.detbox_assign_anchor_workspace_bytes, total_gt), 'assign', st)
         _lib.check(L.detbox_assign_anchor(mode, _ptr(anchors), P, _ptr(gt_boxes), _ptr(gt_labels), _ptr(gt_offsets),
                                           B, total_gt, thr_lo, thr_hi, _ptr(locs), _ptr(labels), _ptr(matched),
                                           _ptr(best), ws.data_ptr(), ws.numel(), st), 'detbox_assign_anchor')
@@ -297,7 +299,7 @@ def select_decode(scores: torch.Tensor, locs: torch.Tensor, anchors: torch.Tenso
     L = _lib.lib()
     with _on(dev):
         st = _stream(dev)
-        ws = _workspace(dev, _ws_bytes(L.detbox_select_decode_workspace_bytes, B, P, C, class_begin, top_k, activation), 'select', st)
+        ws = _workspace(dev, _ws_bytes(dev, L.detbox_select_decode_workspace_bytes, B, P, C, class_begin, top_k, activation), 'select', st)
         _lib.check(L.detbox_select_decode(decode_mode, activation, _ptr(scores), _ptr(extra), _ptr(locs), _ptr(anchors),
                                           B, P, C, class_begin, class_id_offset, conf_thresh, top_k, score_hi_hint,
                                           out_boxes.data_ptr(), out_scores.data_ptr(), out_cls.data_ptr(),
@@ -320,7 +322,7 @@ def nms_segments(boxes: torch.Tensor, scores: torch.Tensor, seg_offsets: torch.T
     L = _lib.lib()
     with _on(dev):
         st = _stream(dev)
-        ws = _workspace(dev, _ws_bytes(L.detbox_batched_nms_segments_workspace_bytes, B, stride, S), 'nms', st)
+        ws = _workspace(dev, _ws_bytes(dev, L.detbox_batched_nms_segments_workspace_bytes, B, stride, S), 'nms', st)
         _lib.check(L.detbox_batched_nms_segments(_ptr(boxes), _ptr(scores), _ptr(seg_offsets), B, stride, S,
                                                  int(max_segment), float(iou_threshold), int(presorted),
                                                  _ptr(keep), kc.data_ptr(), ws.data_ptr(), ws.numel(), st),
@@ -361,7 +363,7 @@ def nms_rows(c: Candidates, iou_threshold: float, image_ids: torch.Tensor, image
     L = _lib.lib()
     with _on(dev):
         st = _stream(dev)
-        ws = _workspace(dev, _ws_bytes(L.detbox_nms_rows_workspace_bytes, B, stride, S), 'nms', st)
+        ws = _workspace(dev, _ws_bytes(dev, L.detbox_nms_rows_workspace_bytes, B, stride, S), 'nms', st)
         _lib.check(L.detbox_nms_rows(_ptr(boxes), _ptr(scores), _ptr(cls), _ptr(seg), B, stride, S,
                                      int(c.top_k if max_segment is None else max_segment), float(iou_threshold), int(presorted),
                                      image_ids.data_ptr(), image_sizes.data_ptr(), _ptr(keep), kc.data_ptr(),

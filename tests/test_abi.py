@@ -34,7 +34,11 @@ def test_library_exports_every_declared_symbol():
     # argument validation happens before any device work, so it is testable here
     assert L.detbox_box_convert(None, None, -1, 0, 0, None) == -1
     assert b'negative' in L.detbox_last_error()
-    assert L.detbox_select_decode_workspace_bytes(16, 120087, 81, 1, 1000, 1) > 16 * 80 * 1000 * 8
+    ws_sel = L.detbox_select_decode_workspace_bytes(16, 120087, 81, 1, 1000, 1)
+    assert ws_sel > 16 * 80 * 1000 * 8                                  # the staging lists
+    # no copy of the activated scores (4*B*P*C bytes) is reserved for the exact path, fused activation or not
+    assert ws_sel < 4 * 16 * 120087 * 81 // 4 and ws_sel == L.detbox_select_decode_workspace_bytes(16, 120087, 81, 1, 1000, 0)
+    assert L.detbox_select_decode_workspace_bytes(512, 120087, 81, 1, 1000, 1) < 4 * 512 * 120087 * 81 // 4
     # one buffer of kept runs (the tile merge reads it once); shapes beyond the tile merge keep the second one
     assert 2 * 4000 * 8 <= L.detbox_batched_nms_segments_workspace_bytes(2, 4000, 20) < 2 * 2 * 4000 * 8
     assert L.detbox_batched_nms_segments_workspace_bytes(2, 40000, 1000) >= 2 * 2 * 40000 * 8

@@ -633,6 +633,46 @@ def test_fused_activation_selection_full_size(D, oracle, dev):
     assert pc[2].numel() == 80 * 1000 and int(torch.cat(pb[2:]).shape[0]) == 80000
 
 
+def test_fused_activation_exact_path_recomputes_scores(D, oracle, dev):
+    """The exact (histogram) path with the activation fused: it keeps no copy of the scores and recomputes them in every
+    pass, so its passes must agree with one another to the bit.  Rows drawn from a handful of patterns make massive ties
+    (exact 64-bit cut-off keys), a constant image makes every class fail the sampled guess, a random image takes the
+    ordinary path beside them.  Three shapes: the sampled path, the short-table path (P < 4096, where the histogram
+    passes are the main path), and the widest head (C = 256, histogram counters added in global memory)."""
+    O = oracle
+    g = torch.Generator().manual_seed(77)
+
+    def run(B, P, C, cb, k, thr, act, pick):
+        anchors = torch.rand(P, 4, generator=g) * 0.5 + 0.2
+        logits = torch.randn(B, P, C, generator=g) * 2
+        patterns = torch.randn(6, C, generator=g) * 2
+        logits[0] = patterns[torch.randint(0, 6, (P,), generator=g)]           # six distinct rows: ties in the thousands
+        if B > 1:
+            logits[1] = 0.25                                                      # every score equal
+        extra = None
+        if act != D.ops.ACT_SOFTMAX:
+            extra = torch.randn(B, P, generator=g)
+            extra[0] = 0.5
+            if B > 1:
+                extra[1] = -0.5
+        locs = torch.randn(B, P, 4, generator=g)
+        ex = None if extra is None else extra.to(dev)
+        scores = D.ops.activate_scores(logits.to(dev), ex, act).cpu()
+        c = D.ops.select_decode(logits.to(dev), locs.to(dev), anchors.to(dev), D.ops.DECODE_CXCYWH, cb, 0, thr, k,
+                                activation=act, extra=ex)
+        counts = c.counts.cpu().tolist()
+        want = oracle_select(O, scores[pick], locs[pick], anchors, 0, cb, 0, thr, k)
+        got = ([c.boxes[b, :counts[b]].cpu() for b in pick], [c.scores[b, :counts[b]].cpu() for b in pick],
+               [c.class_ids[b, :counts[b]].cpu() for b in pick])
+        check_select(got, want)
+
+    run(3, 20000, 21, 1, 300, 0.01, D.ops.ACT_SOFTMAX, [0, 1, 2])
+    run(3, 20000, 6, 0, 1000, 0.02, D.ops.ACT_SIGMOID_SIGMOID, [0, 1, 2])
+    run(3, 24000, 21, 1, 100, 0.001, D.ops.ACT_SOFTMAX_SIGMOID, [0, 1, 2])
+    run(400, 3069, 9, 1, 150, 0.05, D.ops.ACT_SOFTMAX, [0, 1, 399])
+    run(5, 8000, 256, 128, 64, 0.0005, D.ops.ACT_SOFTMAX, [0, 1, 4])
+
+
 # ----------------------------------------------------------------------------- NMS
 
 def rand_boxes(g, n, spread=1.0, size=0.3):

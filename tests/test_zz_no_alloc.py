@@ -68,3 +68,41 @@ def test_noalloc_assign_matches_workspace_entry_point():
     rc = L.detbox_assign_anchor_noalloc(0, a300.data_ptr(), 8732, gbp.data_ptr(), glp.data_ptr(), off.data_ptr(), 12, 65537, 0.5, 0.5,
                                         out.data_ptr(), lab.data_ptr(), lab.data_ptr(), None, None)
     assert rc == -4 and b'65537' in L.detbox_last_error()
+
+
+def test_noalloc_assign_replays_from_a_captured_graph():
+    """The callers this entry point is for: a HIP graph.  The first call on a device looks the scratch array's address
+    up (hipGetSymbolAddress), which is set-up work and not a stream operation, so one eager call per device comes
+    first; after it the entry point is made of a memset and kernel launches only and can be captured and replayed."""
+    import object_detection_amd as D
+    dev = torch.device('cuda', 0)
+    ops, L = D.ops, D.ops._lib.lib()
+    a300 = D.anchors.ssd300_default_boxes().to(dev)
+    gb, gl = _gt(5, 21)
+    _both(D, dev, a300, gb, gl, ops.ASSIGN_CXCYWH, 0.5, 0.5, first=True)        # the eager warm-up call (and a check)
+    gbp, glp, off, total = ops.pack_gt(gb, gl, dev)
+    B, P = len(gb), a300.shape[0]
+    locs = torch.full((B, P, 4), float('nan'), device=dev)
+    labels = torch.full((B, P), -7, dtype=torch.int64, device=dev)
+    matched = torch.full((B, P), -7, dtype=torch.int64, device=dev)
+    best = torch.full((total,), -7, dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream(dev)
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=side):
+        rc = L.detbox_assign_anchor_noalloc(ops.ASSIGN_CXCYWH, a300.data_ptr(), P, gbp.data_ptr(), glp.data_ptr(), off.data_ptr(),
+                                            B, total, 0.5, 0.5, locs.data_ptr(), labels.data_ptr(), matched.data_ptr(),
+                                            best.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    D.ops._lib.check(rc, 'detbox_assign_anchor_noalloc under capture')
+    assert torch.isnan(locs).all() and (labels == -7).all()        # captured, not run
+    for rep in range(2):
+        if rep:                                   # new ground truth in the same buffers: the replay must follow it
+            gb2, gl2 = _gt(5, 21 + rep)
+            g2, l2, o2, t2 = ops.pack_gt(gb2, gl2, dev)
+            if t2 != total:
+                continue
+            gbp.copy_(g2); glp.copy_(l2); off.copy_(o2)
+        graph.replay()
+        torch.cuda.synchronize()
+        wl, wlab, wm, wbest = ops.assign_anchor(a300, gbp, glp, off, total, ops.ASSIGN_CXCYWH, 0.5, 0.5, want_best=True)
+        assert torch.equal(labels, wlab) and torch.equal(matched, wm) and torch.equal(best, wbest) and torch.equal(locs, wl)
