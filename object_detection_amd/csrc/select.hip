@@ -49,6 +49,7 @@ constexpr int SCAN_WAVES = SCAN_BLOCK / 64;  // every wave of a scan workgroup k
 constexpr int SCAN_EBUF = 256;        // most entries of one of a scan wave's two candidate lists in LDS (sp.ebuf: 128 or 256)
 constexpr int SAMPLE_SUBS = 4;        // sampled sub-tiles per workgroup of select_sample
 constexpr int BITMAP_MAX_WORDS = 4096;  // finalize orders by anchor through a P-bit LDS bitmap up to this
+constexpr int CNT_STRIDE = 1;           // words between two (image, class) staging counters (a line each, 32: no faster)
 
 enum { ACT_NONE = 0, ACT_SOFTMAX = 1, ACT_SOFTMAX_SIGMOID = 2, ACT_SIGMOID_SIGMOID = 3 };
 enum { RULE_ALL = 0, RULE_HIST = 1, RULE_EXACT = 2, RULE_STAGED = 3, RULE_PENDING = 4 };
@@ -66,7 +67,7 @@ struct SelRule {
 struct SelParams {
     int P, C, cb, Cs, top_k, cap, shift, tile_anchors;
     int use_sample, sample_rate, sample_m, subs_per_block, n_sub, tile_floats;
-    int ns_cap, scan_gx, ebuf;
+    int ns_cap, scan_gx, ebuf, flush_at;
     long long total_floats;
     float thr;
     uint32_t key_thr;
@@ -117,27 +118,31 @@ __device__ inline float softmax_exp(float x) { return __expf(x); }
 
 // One sub-tile = rows [row_base, row_base+rows) x C of the head output.  It is brought into LDS by
 // LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, no staging registers); the LDS
-// image starts `shift` floats in, so that every 16-byte piece is aligned in both memories.  Two LDS
-// buffers alternate: the DMA of sub-tile s+1 is in flight while sub-tile s is being consumed, and one
-// barrier per sub-tile (which also drains the DMA) separates the roles.  Four lanes share an anchor
-// row; a lane keeps its EPT = ceil(C/4) elements in registers for the whole soft-max.
+// image starts `shift` floats in, so that every 16-byte piece is aligned in both memories.  Four lanes
+// share an anchor row, so a wave works on 16 rows of the sub-tile -- and it brings in exactly those 16
+// rows itself, into two LDS buffers of its own that alternate: the DMA of its part of sub-tile s+1 is in
+// flight while it consumes its part of sub-tile s, and all it ever waits for is its own DMA.  No barrier
+// inside the loop: the four waves of a workgroup drift apart freely, and a wave that is held up (handing
+// its candidates over, say) holds up nobody else.  A lane keeps its EPT = ceil(C/4) elements in registers
+// for the whole soft-max.
 //   ACT_SOFTMAX          score = exp(x - max) / sum                    (ssd300.py:354, retinanet.py:282)
 //   ACT_SOFTMAX_SIGMOID  score = softmax(x) * sigmoid(extra[row])      (fcos.py:314)
 //   ACT_SIGMOID_SIGMOID  score = sigmoid(x) * sigmoid(extra[row])      (yolov3.py:298-300)
-struct SubGeom {
+constexpr int WAVE_ROWS = 64 / LPR;      // anchor rows a wave works on
+
+struct SubGeom {          // this wave's part of a sub-tile
     const float *src;     // 16-byte aligned start of the pieces
-    long long abs0;       // float index of src inside the tensor
-    int shift, nfl, nvec;
+    int shift, nvec;      // floats between src and the first row; 16-byte pieces (0: the wave has no row)
 };
 
 __device__ inline SubGeom sub_geom(const float *in, long long row_base, int rows, int C) {
     SubGeom g;
-    const long long f0 = row_base * C;
+    const int wave = (int)(threadIdx.x >> 6);
+    const int wr = min(WAVE_ROWS, rows - wave * WAVE_ROWS);
+    const long long f0 = (row_base + wave * WAVE_ROWS) * C;
     g.shift = (int)(f0 & 3);
-    g.abs0 = f0 - g.shift;
-    g.src = in + g.abs0;
-    g.nfl = rows * C + g.shift;
-    g.nvec = (g.nfl + 3) >> 2;
+    g.src = in + (f0 - g.shift);
+    g.nvec = wr > 0 ? (wr * C + g.shift + 3) >> 2 : 0;
     return g;
 }
 
@@ -151,13 +156,13 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 // 16 x 120087 x 81 logits, 125 -> 105 us when next to nothing is emitted).
 constexpr int DMA_CPOL = 2;      // 'nt' on gfx950
 template <int EPT>
-__device__ inline void dma_issue(const SubGeom &g, float *s_buf) {
-    const int tid = threadIdx.x, wbase = tid & ~63;
+__device__ inline void dma_issue(const SubGeom &g, float *s_wave) {       // s_wave: the wave's own buffer
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int j = 0; j < EPT / 4 + 1; ++j) {
-        const int v = tid + j * SCAN_BLOCK;
+    for (int j = 0; j < EPT / 4 + 1; ++j) {                              // 16 rows of C <= 4 EPT floats: at most 16 EPT + 2 pieces
+        const int v = lane + j * 64;
         if (v < g.nvec)                                                 // LDS destination = wave-uniform base + lane * 16
-            __builtin_amdgcn_global_load_lds((gptr_t)(g.src + 4 * v), (lptr_t)(s_buf + 4 * (wbase + j * SCAN_BLOCK)), 16, 0, DMA_CPOL);
+            __builtin_amdgcn_global_load_lds((gptr_t)(g.src + 4 * v), (lptr_t)(s_wave + 4 * (j * 64)), 16, 0, DMA_CPOL);
     }
 }
 
@@ -177,15 +182,15 @@ __device__ inline float rescore(const RowCtx &c, int i) {
     return v;
 }
 
-// Scores of this lane's elements of the sub-tile sitting in LDS: x[i] = score of class sub + 4*i of
-// local row threadIdx.x / 4 (meaningless for classes >= C).  Returns false for lanes beyond `rows`.
+// Scores of this lane's elements of the sub-tile: x[i] = score of class sub + 4*i of local row threadIdx.x / 4
+// (meaningless for classes >= C), read from the wave's own buffer s_wave.  Returns false for lanes beyond `rows`.
 template <int ACT, int EPT>
-__device__ inline bool subtile_scores(const float *s_tile, const float *__restrict__ extra, long long row_base,
+__device__ inline bool subtile_scores(const float *s_wave, const float *__restrict__ extra, long long row_base,
                                       int rows, int C, int shift, float (&x)[EPT], RowCtx &ctx) {
     const int r = threadIdx.x / LPR, sub = threadIdx.x % LPR;
-    ctx.row = s_tile; ctx.m = 0.f; ctx.inv = 1.f; ctx.sg = 1.f; ctx.sum = 1.f;
+    ctx.row = s_wave; ctx.m = 0.f; ctx.inv = 1.f; ctx.sg = 1.f; ctx.sum = 1.f;
     if (r >= rows) return false;
-    const float *row = s_tile + shift + r * C + sub;     // the tile has LPR*EPT floats of slack behind it
+    const float *row = s_wave + shift + (r % WAVE_ROWS) * C + sub;     // the buffer has LPR*EPT floats of slack behind it
     ctx.row = row;
     const float fill = (ACT == ACT_SOFTMAX || ACT == ACT_SOFTMAX_SIGMOID) ? -__builtin_inff() : 0.f;
 #pragma unroll
@@ -226,8 +231,9 @@ __device__ inline bool subtile_scores(const float *s_tile, const float *__restri
 }
 
 // Runs f(x, valid, first_anchor_of_subtile, ctx) over sub-tiles first, first+step, ... (< last) of image b
-// with the double-buffered DMA pipeline; after(s) runs once per sub-tile behind the barrier
-// (block-uniform work such as a flush).  s_tiles holds two buffers of tile_floats floats.
+// with the double-buffered DMA pipeline of every wave; after(s) runs once per sub-tile and wave behind f, with no
+// vector-memory operation of the wave in flight.  s_tiles holds two buffers of tile_floats floats, a quarter
+// of each per wave.  The waves are NOT synchronised inside the loop (nor behind it).
 struct NoStart { __device__ void operator()() const {} };
 
 // `start` runs once, after the DMA of the first sub-tile has been issued and before anybody waits for it: the place
@@ -242,28 +248,34 @@ __device__ inline void for_each_subtile(const float *__restrict__ in, const floa
         const int r0 = (int)s * SUB_ROWS;
         return sub_geom(in, (long long)b * P + r0, min(SUB_ROWS, P - r0), C);
     };
+    float *s_wave = s_tiles + (threadIdx.x >> 6) * (tile_floats / SCAN_WAVES);      // this wave's quarter of buffer 0
     SubGeom g = geom(first);
     int buf = 0;
-    dma_issue<EPT>(g, s_tiles);
+    dma_issue<EPT>(g, s_wave);
     start();
-    __syncthreads();
+    __syncthreads();             // (the one barrier: it also waits for the first DMA)
     started();                   // what start() left in LDS is visible
     for (long long s = first; s < last; s += step) {
         const bool more = s + step < last;
         SubGeom gn = g;
         if (more) {
             gn = geom(s + step);
-            dma_issue<EPT>(gn, s_tiles + (buf ^ 1) * tile_floats);
+            dma_issue<EPT>(gn, s_wave + (buf ^ 1) * tile_floats);
         }
         const int r0 = (int)s * SUB_ROWS;
         const int rows = min(SUB_ROWS, P - r0);
         float x[EPT];
         RowCtx ctx;
-        const bool valid = subtile_scores<ACT, EPT>(s_tiles + buf * tile_floats, extra, (long long)b * P + r0, rows, C,
+        const bool valid = subtile_scores<ACT, EPT>(s_wave + buf * tile_floats, extra, (long long)b * P + r0, rows, C,
                                                     g.shift, x, ctx);
         f(x, valid, r0, ctx);
-        __syncthreads();          // sub-tile s consumed by every wave, DMA of the next one landed
-        after(s);                 // (behind the next sub-tile's DMA issue instead, the scan's hand-over costs 12 us more)
+        // the wave's part of the next sub-tile has landed, and nothing of sub-tile s is read from LDS behind this point
+        // (the builtin, not inline assembly: the compiler's own wait-count bookkeeping then knows that no LDS-DMA is pending and
+        // does not wait again in front of later LDS accesses)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0070);           // vmcnt(0) lgkmcnt(0)
+        asm volatile("" ::: "memory");
+        after(s);                 // what it issues has the whole next sub-tile to complete before the wave waits again
         g = gn;
         buf ^= 1;
     }
@@ -460,7 +472,7 @@ __global__ __launch_bounds__(BLK) void select_plan_kernel(const float *__restric
     r.pad = 0; r.cutoff = 0ull; r.n_above = 0; r.n_sel = 0;
     // first kernel of a call: the counters and flags the later kernels add to start from zero
     if (tid == 0) {
-        gcnt[(size_t)b * sp.Cs + ci] = 0u;
+        gcnt[((size_t)b * sp.Cs + ci) * CNT_STRIDE] = 0u;
         if (ci == 0) img_ovf[b] = 0u;
         if (ci == 0 && b == 0) *flag = sp.use_sample ? 0u : 1u;
     }
@@ -578,8 +590,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
     // Every wave collects its candidates in an LDS list of its own (no atomics, a wave-uniform count) and hands full lists
     // straight to the per-(image, class) staging lists: the entries of a list are counted per class in LDS, one global
     // atomic per class present reserves their places, and the entries are scattered there.  The hand-over is split over
-    // two sub-tiles -- the atomics are issued behind one barrier, their results used behind the next, which waits for
-    // the sub-tile's DMA anyway -- and the wave fills its second list meanwhile, so nothing ever waits for an atomic.
+    // two sub-tiles -- the atomics are issued behind the wave's wait for one sub-tile's DMA, their results used behind its
+    // wait for the next, which they have returned by -- and the wave fills its second list meanwhile.
     const int wv = tid >> 6;
     const uint32_t ebuf_n = (uint32_t)sp.ebuf;            // entries per list: 256, or 128 where the sub-tiles are small and
                                                           // more workgroups share a CU
@@ -590,48 +602,69 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
     uint32_t *wc = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned long long *>(s_dynf + 2 * (size_t)sp.tile_floats + 4) + (size_t)SCAN_WAVES * 2 * ebuf_n)
                    + (size_t)wv * (two_rows ? 128 : 64);
     unsigned long long *stg = staging + (size_t)b * Cs * sp.cap;
-    uint32_t *gc = gcnt + (size_t)b * Cs;
+    uint32_t *gc = gcnt + (size_t)b * Cs * CNT_STRIDE;
     const uint32_t cap = (uint32_t)sp.cap;
     uint32_t ln = 0, pn = 0;                              // entries waiting in the current list; entries of the list being handed over
     uint32_t pmeta[SCAN_EBUF / 64], gbase0 = 0, gbase1 = 0;
-    auto flush_begin = [&]() {                            // pn == 0
+    // Both halves are written without a branch around their LDS accesses (a lane beyond the list's end reads a slot of the
+    // list all the same and adds zero to counter 0): the four rounds' reads, and then their atomics, are independent
+    // instructions in flight together -- one LDS round trip per step instead of one per round and step.
+    auto flush_begin = [&](uint32_t &g0, uint32_t &g1) {  // pn == 0; g0 / g1 receive the bases of the lane's classes
         wc[lane] = 0u;
         if (two_rows) wc[lane + 64] = 0u;
+        uint32_t ci[SCAN_EBUF / 64], old[SCAN_EBUF / 64];
 #pragma unroll
         for (int j = 0; j < SCAN_EBUF / 64; ++j) {
-            const uint32_t k = (uint32_t)lane + 64u * j;
-            pmeta[j] = 0u;
-            if (k < ln) {
-                const uint32_t ci = (uint32_t)(ebuf[k] >> 24) & 0xffu;
-                pmeta[j] = (ci << 16) | atomicAdd(&wc[ci], 1u);           // place among the list's entries of that class
-            }
+            const uint32_t k = (uint32_t)lane + 64u * j;                  // (k < 256: inside the wave's two lists either way)
+            const uint32_t lo = reinterpret_cast<const uint32_t *>(ebuf)[2u * k];
+            ci[j] = k < ln ? (lo >> 24) : 0u;
         }
+#pragma unroll
+        for (int j = 0; j < SCAN_EBUF / 64; ++j)
+            old[j] = atomicAdd(&wc[ci[j]], (uint32_t)lane + 64u * j < ln ? 1u : 0u);   // place among the list's entries of that class
+#pragma unroll
+        for (int j = 0; j < SCAN_EBUF / 64; ++j)
+            pmeta[j] = (uint32_t)lane + 64u * j < ln ? (ci[j] << 16) | old[j] : 0u;
         const uint32_t c0 = wc[lane], c1 = two_rows ? wc[lane + 64] : 0u;
-        gbase0 = c0 ? atomicAdd(&gc[lane], c0) : 0u;                      // c0 != 0 only for lane < Cs
-        gbase1 = c1 ? atomicAdd(&gc[lane + 64], c1) : 0u;
+        g0 = c0 ? atomicAdd(&gc[lane * CNT_STRIDE], c0) : 0u;             // c0 != 0 only for lane < Cs
+        g1 = c1 ? atomicAdd(&gc[(lane + 64) * CNT_STRIDE], c1) : 0u;
         unsigned long long *t = ebuf; ebuf = pbuf; pbuf = t;
         pn = ln;
         ln = 0u;
     };
-    auto flush_end = [&]() {
+    auto flush_end = [&](const uint32_t g0, const uint32_t g1) {
         if (pn == 0u) return;
-        wc[lane] = gbase0;
-        if (two_rows) wc[lane + 64] = gbase1;
+        wc[lane] = g0;
+        if (two_rows) wc[lane + 64] = g1;
+        unsigned long long en[SCAN_EBUF / 64];
+        uint32_t base[SCAN_EBUF / 64];
+#pragma unroll
+        for (int j = 0; j < SCAN_EBUF / 64; ++j) {
+            en[j] = pbuf[(uint32_t)lane + 64u * j];
+            base[j] = wc[pmeta[j] >> 16];
+        }
 #pragma unroll
         for (int j = 0; j < SCAN_EBUF / 64; ++j) {
             const uint32_t k = (uint32_t)lane + 64u * j;
-            if (k < pn) {
-                const unsigned long long en = pbuf[k];
-                const uint32_t ci = pmeta[j] >> 16;
-                const uint32_t pos = wc[ci] + (pmeta[j] & 0xffffu);
-                const uint32_t p = (uint32_t)en & 0xffffffu;
-                // a list that overflows keeps counting: select_check sees the count and hands the pair to the exact path
-                if (pos < cap) stg[(size_t)ci * cap + pos] = (en & 0xffffffff00000000ull) | (unsigned long long)(0xffffffffu - p);
-            }
+            const uint32_t ci = pmeta[j] >> 16;
+            const uint32_t pos = base[j] + (pmeta[j] & 0xffffu);
+            const uint32_t p = (uint32_t)en[j] & 0xffffffu;
+            // a list that overflows keeps counting: select_check sees the count and hands the pair to the exact path
+            if (k < pn && pos < cap) stg[(size_t)ci * cap + pos] = (en[j] & 0xffffffff00000000ull) | (unsigned long long)(0xffffffffu - p);
         }
         pn = 0u;
     };
-    auto flush = [&]() { flush_end(); flush_begin(); flush_end(); };       // inside a sub-tile: waits for its own atomics
+    // Inside a sub-tile (a list that cannot take the sub-tile's entries: rare): completes the hand-over in flight and makes
+    // one of its own, waiting for its atomics.  It writes to bases of its own: gbase0 / gbase1, which an atomic in flight
+    // may still be about to write, are assigned behind the wave's wait for its DMA only -- were they assigned here as
+    // well, the copies the compiler then makes of them on the way into this code would each wait for every load in flight,
+    // the sub-tile's DMA included, in every sub-tile.
+    auto flush = [&]() {
+        flush_end(gbase0, gbase1);
+        uint32_t t0 = 0u, t1 = 0u;
+        flush_begin(t0, t1);
+        flush_end(t0, t1);
+    };
     // the lane's classes never change: their staging thresholds live in registers (fetched into LDS by the first Cs
     // threads while the first sub-tile's DMA is in flight, then picked up by every lane)
     const int r = tid / LPR, sub = tid % LPR;
@@ -669,8 +702,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
             if (!valid) { pm_lo = 0u; pm_hi = 0u; }
             // Every lane's entries get consecutive slots of the wave's LDS buffer: popcount per lane, prefix sum over the wave
             // (the order of the entries inside the list is irrelevant), then each lane writes its own entries.  A global store
-            // inside the loop would be waited for at the sub-tile's barrier (the counter that tells the tile's DMA has landed
-            // counts stores as well), once per sub-tile; the buffer is flushed once per dozen sub-tiles instead.
+            // inside the loop would be waited for with the sub-tile's DMA (the counter that tells the DMA has landed counts
+            // stores as well), once per sub-tile; the buffer is flushed once per dozen sub-tiles instead.
             uint32_t cnt = (uint32_t)__popc(pm_lo) + (EPT > 32 ? (uint32_t)__popc(pm_hi) : 0u);
             if (__ballot(cnt != 0u) != 0ull) {
                 const uint32_t inc = wave_inclusive_add(cnt);
@@ -714,10 +747,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_scan_kernel(const float *__
                 }
             }
         },
-        // behind the barrier: the atomics and the stores have the whole next sub-tile to complete before a barrier waits for them
+        // behind the wave's wait: the atomics and the stores have the whole next sub-tile to complete before it waits again
         [&](long long) {
-            flush_end();
-            if (ln >= ebuf_n / 2u) flush_begin();
+            flush_end(gbase0, gbase1);
+            if (ln >= (uint32_t)sp.flush_at) flush_begin(gbase0, gbase1);
         }, fetch_thresholds, load_thresholds);
     flush();
 }
@@ -731,13 +764,13 @@ __global__ __launch_bounds__(128) void select_check_kernel(SelParams sp, SelRule
     if (ci < sp.Cs) {
         SelRule *r = rules + (size_t)b * sp.Cs + ci;
         if (r->mode == RULE_STAGED) {
-            const uint32_t n = gcnt[(size_t)b * sp.Cs + ci];
+            const uint32_t n = gcnt[((size_t)b * sp.Cs + ci) * CNT_STRIDE];
             const bool ok = !img_ovf[b] && n <= (uint32_t)sp.cap && (r->beta != 0u || n >= (uint32_t)sp.top_k);
             if (ok) {
                 r->n_sel = n < (uint32_t)sp.top_k ? n : (uint32_t)sp.top_k;
             } else {
                 r->mode = RULE_PENDING;
-                gcnt[(size_t)b * sp.Cs + ci] = 0u;
+                gcnt[((size_t)b * sp.Cs + ci) * CNT_STRIDE] = 0u;
                 atomicOr(flag, 1u);
                 pending = true;
             }
@@ -953,7 +986,7 @@ __global__ __launch_bounds__(PASS_BLOCK) void select_emit_kernel(const float *__
             if (r.mode == RULE_HIST) take = bin_of((uint32_t)(K >> 32), shift) >= r.beta;
             else if (r.mode == RULE_EXACT) take = K >= r.cutoff;
             if (take) {
-                const uint32_t slot = atomicAdd(&cnt[(size_t)b * sp.Cs + ci], 1u);
+                const uint32_t slot = atomicAdd(&cnt[((size_t)b * sp.Cs + ci) * CNT_STRIDE], 1u);
                 if (slot < (uint32_t)cap) staging[((size_t)b * sp.Cs + ci) * cap + slot] = K;
             }
         }
@@ -1153,7 +1186,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void select_emit_fused_kernel(const flo
                     if (rl.mode == RULE_HIST) take = bin_of((uint32_t)(K >> 32), shift) >= rl.beta;
                     else if (rl.mode == RULE_EXACT) take = K >= rl.cutoff;
                     if (take) {
-                        const uint32_t slot = atomicAdd(&cnt[(size_t)b * Cs + ci], 1u);
+                        const uint32_t slot = atomicAdd(&cnt[((size_t)b * Cs + ci) * CNT_STRIDE], 1u);
                         if (slot < (uint32_t)cap) staging[((size_t)b * Cs + ci) * cap + slot] = K;
                     }
                 }
@@ -1235,7 +1268,7 @@ __global__ __launch_bounds__(BLK) void select_finalize_kernel(
     const size_t bc = (size_t)b * sp.Cs + ci;
     const int n_sel = (int)rules[bc].n_sel;
     if (n_sel == 0) return;
-    int n_stage = (int)cnt[bc];
+    int n_stage = (int)cnt[bc * CNT_STRIDE];
     if (n_stage > sp.cap) n_stage = sp.cap;
     const int take = min(n_sel, n_stage);
     const unsigned long long *st = staging + bc * sp.cap;
@@ -1645,7 +1678,8 @@ int ept_for(int64_t C) { return (C <= 32 ? 32 : (C <= 96 ? 96 : (C <= 128 ? 128 
 
 // LDS floats of one sub-tile: the data, the alignment shift, and 4*EPT floats of slack so that the
 // unconditional register loads of the activation stay inside the buffer.
-int tile_floats_for(int64_t C) { return (int)(((SUB_ROWS * C + LPR * ept_for(C) + 8) / 4 + 1) * 4); }
+// (a quarter per wave: its 16 rows, the alignment shift and the slack, in whole 16-byte pieces)
+int tile_floats_for(int64_t C) { return SCAN_WAVES * (int)(((WAVE_ROWS * C + LPR * ept_for(C) + 8) / 4 + 1) * 4); }
 
 // Entries of each of a scan wave's two candidate lists: 256, or 128 where the sub-tiles are small (few classes), many
 // workgroups share a CU and the lists would otherwise be most of a workgroup's LDS.
@@ -1759,7 +1793,7 @@ SelLayout layout(int64_t B, int64_t P, int64_t C, int64_t Cs, const SelPlan &pl)
         return L;
     }
     L.hist = off; off = align_up(off + (size_t)B * Cs * NB * sizeof(uint32_t), 256);
-    L.cnt = off; off = align_up(off + (size_t)B * Cs * sizeof(uint32_t), 256);
+    L.cnt = off; off = align_up(off + (size_t)B * Cs * CNT_STRIDE * sizeof(uint32_t), 256);
     L.flag = off; off = align_up(off + sizeof(uint32_t), 256);
     L.img_ovf = off; off = align_up(off + (size_t)B * sizeof(uint32_t), 256);
     L.rules = off; off = align_up(off + (size_t)B * Cs * sizeof(SelRule), 256);
@@ -2052,6 +2086,14 @@ extern "C" int detbox_select_decode(int decode_mode, int activation, const float
     sp.subs_per_block = plan.subs_per_block; sp.scan_gx = plan.scan_gx;
     sp.tile_floats = tile_floats_for(C);
     sp.ebuf = scan_ebuf_for(C);
+    {
+        // A hand-over costs the wave about 1.5 us whatever it carries (the wave's next wait for its DMA also waits for the
+        // hand-over's atomics, which take longer than a sub-tile), so lists are handed over three quarters full rather than
+        // half full: 143 -> 137 us on the dense RetinaNet-800 batch (1/8: 190, 1/4: 157, 7/8: 136, where a sub-tile's
+        // candidates begin not to fit and are handed over inside the sub-tile).  DETBOX_SCAN_FLUSH_AT=1..8 (eighths) overrides.
+        static const int eighths = [] { const char *e = std::getenv("DETBOX_SCAN_FLUSH_AT"); const int v = e ? std::atoi(e) : 0; return v > 0 && v <= 8 ? v : 6; }();
+        sp.flush_at = sp.ebuf * eighths / 8;
+    }
     sp.total_floats = (long long)B * P * C;
 
     if (use_direct(B, P, C)) {

@@ -11,7 +11,7 @@ g = torch.Generator(device=dev).manual_seed(0)
 locs = torch.randn(B, P, 4, device=dev, generator=g)
 confs = torch.randn(B, P, C, device=dev, generator=g)
 anch = m.pboxes.to(dev)
-names = ['select_sample', 'select_plan', 'select_scan', 'select_bucket', 'select_check', 'select_finalize', 'nms_segments', 'nms_merge', 'activate_scores']
+names = ['select_sample', 'select_plan', 'select_scan', 'select_check', 'select_finalize', 'nms_segments', 'nms_merge', 'activate_scores']
 
 def run(tag, fn, n=5):
     for _ in range(2): fn()
