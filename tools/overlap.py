@@ -77,6 +77,17 @@ def main():
     res['pair'] = {'a': args.a, 'b': args.b, 'a_us': ta / 1e3, 'b_us': tb / 1e3, 'both_us': tab / 1e3}
     print(f'{args.a}: {ta / 1e3:.0f} us, {args.b}: {tb / 1e3:.0f} us, both on the chip: {tab / 1e3:.0f} us '
           f'({100 * tab / max(min(ta, tb), 1):.0f} % of the shorter)')
+    # every pair of the eight kernels with the most busy time: how long both were on the chip
+    big = [k for k, _ in sorted(by.items(), key=lambda kv: -sum(e - s for s, e in kv[1]))[:8]]
+    un = {k: union(by[k]) for k in big}
+    res['pairs_us'] = {}
+    print('both on the chip (us):')
+    for i, ka in enumerate(big):
+        for kb in big[i + 1:]:
+            t = inter(un[ka], un[kb]) / 1e3
+            res['pairs_us'][ka + ' | ' + kb] = t
+            if t >= 1.0:
+                print(f'  {ka:24s} {kb:24s} {t:9.0f}')
     sum_all = sum(e - s for _, s, e in rows)
     res['sum_of_kernel_durations_us'] = sum_all / 1e3
     print(f'sum of kernel durations {sum_all / 1e3:.0f} us = {sum_all / max(busy, 1):.2f} x the busy time')
