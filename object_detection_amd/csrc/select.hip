@@ -1871,8 +1871,13 @@ struct LaunchFast {
             // (a workgroup's packed 16-bit counters hold fewer than 65536 anchors: at most 1023 sub-tiles each)
             const unsigned gxh = (unsigned)std::max<int64_t>(gx, (sp.n_sub + 1022) / 1023);
             {
+                // Behind the scan these launches almost always return at once -- but a workgroup must be given its LDS before it
+                // can look at the flag, and with other batches' scan or NMS workgroups on every CU a large request waits for
+                // them to drain (12-17 us per launch instead of 4.5, with three batches in flight).  So the passes ask for
+                // little there: counters added in global memory, 16 tied classes at a time.  Where the exact path is the main
+                // path (short tables: no scan) they take the LDS they can use.
                 const size_t hist_bytes = (size_t)sp.Cs * (NB / 2) * 4;
-                const int lds_hist = 2 * tile_bytes + hist_bytes <= FUSED_LDS_BUDGET ? 1 : 0;
+                const int lds_hist = !sp.use_sample && 2 * tile_bytes + hist_bytes <= FUSED_LDS_BUDGET ? 1 : 0;
                 const size_t lds = 2 * tile_bytes + (lds_hist ? hist_bytes : 0);
                 if (int rc = set_lds(score_hist_fused_kernel<ACT, EPT>, lds)) return rc;
                 ProfScope ps("score_hist", s);
@@ -1886,7 +1891,8 @@ struct LaunchFast {
                 DETBOX_LAUNCH_CHECK();
             }
             {
-                int group = (int)((FUSED_LDS_BUDGET - 2 * tile_bytes) / 1024);
+                int group = sp.use_sample ? 16 : (int)((FUSED_LDS_BUDGET - 2 * tile_bytes) / 1024);
+                if (2 * tile_bytes + (size_t)group * 1024 > FUSED_LDS_BUDGET) group = (int)((FUSED_LDS_BUDGET - 2 * tile_bytes) / 1024);
                 if (group > sp.Cs) group = sp.Cs;
                 if (group < 1) group = 1;
                 const size_t lds = 2 * tile_bytes + (size_t)group * 1024;
