@@ -36,7 +36,7 @@ constexpr int NMS_LDS_BOXES = 4096;       // segments up to this length keep the
 constexpr int NMS_MAX_SEGMENT = 262144;   // bitmap limit for presorted segments
 
 struct NmsParams {
-    int S, max_seg, n2, in_lds, presorted, thr_neg, stats;
+    int S, max_seg, n2, in_lds, presorted, thr_neg, stats, network_sort;
     long long stride;
     float thr;
 };
@@ -728,6 +728,96 @@ __device__ unsigned long long g_pair_stats[8];
 
 struct NmsPairLds { size_t box, q, irec, removed, mask, misc, wprefix, rank, win, total; };
 
+// Score order of a segment by a distribution sort instead of the bitonic network (four-wave form).  The keys of a class's
+// candidates lie in a narrow, smoothly filled range, so a linear map of the score key onto RS_NB buckets leaves about one
+// key per bucket: one LDS atomic per key counts the buckets, a prefix sum places them, the keys are scattered, and a key's
+// rank is its bucket's start plus the number of larger keys in its bucket.  Some dozens of instructions per key and seven
+// barriers, against the 55 compare-exchange stages of the network (27 k of an 1000-box segment's 50 k cycles up to the
+// records).  Keys that pile up (equal scores: more than RS_BUCKET_MAX in a bucket) leave the segment to the network.
+constexpr int RS_NB = 1024;
+constexpr int RS_BUCKET_MAX = 32;
+
+template <int O>
+__device__ inline uint32_t rs_wave_min(uint32_t v) {
+    v = min(v, lane_xor_u32<O>(v));
+    if constexpr (O > 1) return rs_wave_min<O / 2>(v);
+    else return v;
+}
+
+// rank[m] = descending rank of K[m] (the key of element tid + m * BLK, distinct keys; elements beyond n are ignored).
+// s_b: n words of scratch; s_hist: RS_NB + 16 words.  Returns false (block-uniform) when a bucket is too full.
+template <int JPT, int BLK>
+__device__ inline bool rank_by_buckets(const unsigned long long (&K)[JPT], const int n, unsigned long long *__restrict__ s_b,
+                                       uint32_t *__restrict__ s_hist, uint32_t (&rank)[JPT]) {
+    static_assert(RS_NB % BLK == 0, "buckets per thread");
+    constexpr int BPT = RS_NB / BLK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t *s_min = s_hist + RS_NB, *s_max = s_hist + RS_NB + 1, *s_big = s_hist + RS_NB + 2, *s_w = s_hist + RS_NB + 4;
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
+#pragma unroll
+    for (int m = 0; m < JPT; ++m)
+        if (tid + m * BLK < n) { kmin = min(kmin, (uint32_t)(K[m] >> 32)); kmax = max(kmax, (uint32_t)(K[m] >> 32)); }
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) s_hist[tid + q * BLK] = 0u;
+    if (tid == 0) { *s_min = 0xffffffffu; *s_max = 0u; *s_big = 0u; }
+    __syncthreads();
+    kmin = rs_wave_min<32>(kmin);
+    kmax = ~rs_wave_min<32>(~kmax);
+    if (lane == 0) { atomicMin(s_min, kmin); atomicMax(s_max, kmax); }
+    __syncthreads();
+    const uint32_t hi = *s_max, width = hi - *s_min;
+    // monotone in the key: int -> float rounding, the product with a positive scale and the truncation all are
+    const float scale = width ? (float)(RS_NB - 1) / (float)width : 0.0f;
+    int bucket[JPT];
+    uint32_t slot[JPT];
+#pragma unroll
+    for (int m = 0; m < JPT; ++m) {
+        bucket[m] = min(RS_NB - 1, (int)((float)(hi - (uint32_t)(K[m] >> 32)) * scale));
+        slot[m] = 0u;
+        if (tid + m * BLK < n) slot[m] = atomicAdd(&s_hist[bucket[m]], 1u);
+        else bucket[m] = RS_NB - 1;
+    }
+    __syncthreads();
+    {   // exclusive prefix sums of the bucket counts, in place; the largest count
+        uint32_t c[BPT], sum = 0u, big = 0u;
+#pragma unroll
+        for (int q = 0; q < BPT; ++q) { c[q] = s_hist[tid * BPT + q]; sum += c[q]; big = max(big, c[q]); }
+        const uint32_t inc = wave_inclusive_add(sum);
+        if (lane == 63) s_w[wave] = inc;
+        if (big > (uint32_t)RS_BUCKET_MAX) *s_big = 1u;
+        __syncthreads();
+        uint32_t base = inc - sum;
+#pragma unroll
+        for (int w = 0; w < BLK / 64; ++w) base += w < wave ? s_w[w] : 0u;
+#pragma unroll
+        for (int q = 0; q < BPT; ++q) { s_hist[tid * BPT + q] = base; base += c[q]; }
+    }
+    __syncthreads();
+    if (*s_big) return false;
+#pragma unroll
+    for (int m = 0; m < JPT; ++m)
+        if (tid + m * BLK < n) s_b[s_hist[bucket[m]] + slot[m]] = K[m];
+    __syncthreads();
+    int bs[JPT], len[JPT], ahead[JPT], longest = 0;
+#pragma unroll
+    for (int m = 0; m < JPT; ++m) {
+        bs[m] = (int)s_hist[bucket[m]];
+        len[m] = tid + m * BLK < n ? (bucket[m] + 1 < RS_NB ? (int)s_hist[bucket[m] + 1] : n) - bs[m] : 0;
+        ahead[m] = 0;
+        longest = max(longest, len[m]);
+    }
+    for (int j = 0; j < longest; ++j) {              // the thread's keys walk their buckets together: the LDS reads overlap
+#pragma unroll
+        for (int m = 0; m < JPT; ++m) {
+            const unsigned long long x = s_b[min(bs[m] + j, n - 1)];
+            ahead[m] += (j < len[m] && x > K[m]) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < JPT; ++m) rank[m] = (uint32_t)(bs[m] + ahead[m]);
+    return true;
+}
+
 // Entries per wave queue.  A queue that fills up is drained (tested pairs leave, true edges stay at its front); a window
 // that passes more pairs than are free is appended one box i at a time (at most 64 * JPT pairs each); the segment goes to
 // the chunked algorithm once the true edges of a wave leave no room for that.  With 1000-box segments the whole layout is
@@ -749,7 +839,11 @@ __host__ __device__ inline NmsPairLds nms_pair_lds(int max_seg, int n2, int blk)
     size_t off = 0;
     const size_t xch = blk > 64 ? (size_t)(n2 > blk ? n2 : blk) * 8 : 0;          // sort exchange buffer, dead before the boxes arrive
     const size_t boxes = (size_t)max_seg * 16;                                    // the boxes in sorted order, for the exact test
-    l.box = off;     off += boxes > xch ? boxes : xch;
+    // (four-wave form: the rank sort scatters the keys into the first max_seg words and keeps its bucket counters behind them)
+    const size_t rsort = blk > 64 ? (((size_t)max_seg * 8 + 15) & ~(size_t)15) + (size_t)(RS_NB + 16) * 4 : 0;
+    size_t box_bytes = boxes > xch ? boxes : xch;
+    if (rsort > box_bytes) box_bytes = rsort;
+    l.box = off;     off += box_bytes;
     const size_t queues = (size_t)(blk / 64) * PAIR_QCAP * 4;
     // rank -> row inside the segment (2048 bytes: at most 1024 boxes), then the bins of the counting sort; both dead before the queues fill
     const size_t orig = blk > 64 ? 2048 + (size_t)PAIR_BINS_PAD * 4 : (((size_t)max_seg * 2 + 15) & ~(size_t)15);
@@ -827,11 +921,26 @@ __device__ inline bool nms_pairs_body(
                 K[m] = ((unsigned long long)okey_from_bits(__float_as_uint(scores[row0 + i] + 0.0f)) << 32) |
                        (unsigned long long)(0xffffffffu - (uint32_t)i);
         }
-        bitonic_desc_u64_regs<JPT, BLK>(K, s_keys, n2, tid);
+        bool ranked = false;
+        if constexpr (BLK > 64) if (!np.network_sort) {
+            uint32_t rk[JPT];
+            uint32_t *s_hist = reinterpret_cast<uint32_t *>(lds_base + ld.box + ((((size_t)np.max_seg * 8 + 15) & ~(size_t)15)));
+            ranked = rank_by_buckets<JPT, BLK>(K, n, s_keys, s_hist, rk);
+            if (ranked) {
 #pragma unroll
-        for (int m = 0; m < JPT; ++m) {
-            const int i = tid + m * BLK;
-            if (i < n) s_orig[i] = (uint16_t)(0xffffffffu - (uint32_t)(K[m] & 0xffffffffull));
+                for (int m = 0; m < JPT; ++m) {
+                    const int i = tid + m * BLK;
+                    if (i < n) s_orig[rk[m]] = (uint16_t)i;
+                }
+            }
+        }
+        if (!ranked) {
+            bitonic_desc_u64_regs<JPT, BLK>(K, s_keys, n2, tid);
+#pragma unroll
+            for (int m = 0; m < JPT; ++m) {
+                const int i = tid + m * BLK;
+                if (i < n) s_orig[i] = (uint16_t)(0xffffffffu - (uint32_t)(K[m] & 0xffffffffull));
+            }
         }
     }
     for (int i = tid; i < words; i += BLK) s_removed[i] = 0ull;
@@ -1589,6 +1698,8 @@ __global__ __launch_bounds__(256) void pack_wire_kernel(
 
 // DETBOX_NMS_CHUNKED=1 (measurements, tests): always the chunked kernel, never the pair-list one
 const bool g_nms_chunked_only = std::getenv("DETBOX_NMS_CHUNKED") != nullptr;
+// DETBOX_NMS_NETWORK_SORT=1 (measurements, tests): the pair-list kernel always orders a segment with the bitonic network
+const bool g_nms_network_sort = std::getenv("DETBOX_NMS_NETWORK_SORT") != nullptr;
 // DETBOX_NMS_STATS=1: the pair-list kernel adds to the counters detbox_debug_nms_stats reads (a few atomics per wave)
 bool g_nms_stats = std::getenv("DETBOX_NMS_STATS") != nullptr;     // also switched by detbox_debug_nms_stats_enable
 
@@ -1675,6 +1786,7 @@ int nms_run(const float *boxes, const float *scores, const int32_t *seg_offsets,
     np.thr = t32;
     np.thr_neg = iou_threshold < 0.0 ? 1 : 0;
     np.stats = g_nms_stats ? 1 : 0;
+    np.network_sort = g_nms_network_sort ? 1 : 0;
     const bool fast = !np.presorted && !np.thr_neg && max_segment <= DETBOX_NMS_MAX_SORT;
     {
         ProfScope ps("nms_segments", st);
