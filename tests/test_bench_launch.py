@@ -85,3 +85,24 @@ def test_two_ranks_rehearsal_on_one_gpu():
             assert ex['payload'] == 'header' and ex['bytes_in_per_step_per_rank'] < 24 * 64     # headers only: a few rows
         else:
             assert ex['payload'] == 'rows' and ex['bytes_in_per_step_per_rank'] > 24 * d['config']['kept_per_image']
+
+
+def test_stale_counters_never_reach_the_line(monkeypatch):
+    """profiles/traffic.json and profiles/valu.json carry the hash of the kernel sources they were counted on; bench.py
+    reports them only while that hash is the tree's (a counter pass of other kernels prints as null)."""
+    import bench
+    from object_detection_amd import build
+    with open(os.path.join(bench.REPO, 'profiles', 'traffic.json')) as f:
+        stamp = json.load(f)['retinanet800/dense']['_source_sha256']
+    assert len(stamp) == 64
+    monkeypatch.setattr(build, 'source_hash', lambda: stamp)
+    t = bench.measured_traffic('retinanet800', 'dense', 'select_scan')
+    assert t is not None and 6.0e8 < t < 7.5e8                  # about the 622 MB of logits a scan launch reads
+    v = bench.measured_valu('retinanet800', 'dense')
+    assert v is not None and v['valu_insts_per_launch'] > 1e7
+    f = bench.valu_fields(v, 90.0)
+    assert 0.0 < f['valu_frac'] < f['valu_frac_if_all_half_rate'] < 1.0
+    monkeypatch.setattr(build, 'source_hash', lambda: '0' * 64)          # any kernel edit changes the hash
+    assert bench.measured_traffic('retinanet800', 'dense', 'select_scan') is None
+    assert bench.measured_valu('retinanet800', 'dense') is None
+    assert bench.measured_traffic('retinanet800', 'nowhere', 'select_scan') is None
