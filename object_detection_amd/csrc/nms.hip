@@ -728,14 +728,15 @@ __device__ unsigned long long g_pair_stats[8];
 
 struct NmsPairLds { size_t box, q, irec, removed, mask, misc, wprefix, rank, win, total; };
 
-// Score order of a segment by a distribution sort instead of the bitonic network (four-wave form).  The keys of a class's
+// Score order of a segment by a distribution sort instead of the bitonic network.  The keys of a class's
 // candidates lie in a narrow, smoothly filled range, so a linear map of the score key onto RS_NB buckets leaves about one
 // key per bucket: one LDS atomic per key counts the buckets, a prefix sum places them, the keys are scattered, and a key's
 // rank is its bucket's start plus the number of larger keys in its bucket.  Some dozens of instructions per key and seven
 // barriers, against the 55 compare-exchange stages of the network (27 k of an 1000-box segment's 50 k cycles up to the
 // records).  Keys that pile up (equal scores: more than RS_BUCKET_MAX in a bucket) leave the segment to the network.
-constexpr int RS_NB = 1024;
+constexpr int RS_NB = 1024;            // buckets of the four-wave form (up to 1024 keys); the single-wave form (up to 256) takes 256
 constexpr int RS_BUCKET_MAX = 32;
+__host__ __device__ constexpr int rs_buckets(int blk) { return blk > 64 ? RS_NB : 256; }
 
 template <int O>
 __device__ inline uint32_t rs_wave_min(uint32_t v) {
@@ -749,6 +750,7 @@ __device__ inline uint32_t rs_wave_min(uint32_t v) {
 template <int JPT, int BLK>
 __device__ inline bool rank_by_buckets(const unsigned long long (&K)[JPT], const int n, unsigned long long *__restrict__ s_b,
                                        uint32_t *__restrict__ s_hist, uint32_t (&rank)[JPT]) {
+    constexpr int RS_NB = rs_buckets(BLK);           // (shadows the four-wave constant on purpose)
     static_assert(RS_NB % BLK == 0, "buckets per thread");
     constexpr int BPT = RS_NB / BLK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -839,8 +841,8 @@ __host__ __device__ inline NmsPairLds nms_pair_lds(int max_seg, int n2, int blk)
     size_t off = 0;
     const size_t xch = blk > 64 ? (size_t)(n2 > blk ? n2 : blk) * 8 : 0;          // sort exchange buffer, dead before the boxes arrive
     const size_t boxes = (size_t)max_seg * 16;                                    // the boxes in sorted order, for the exact test
-    // (four-wave form: the rank sort scatters the keys into the first max_seg words and keeps its bucket counters behind them)
-    const size_t rsort = blk > 64 ? (((size_t)max_seg * 8 + 15) & ~(size_t)15) + (size_t)(RS_NB + 16) * 4 : 0;
+    // (the rank sort scatters the keys into the first max_seg words and keeps its bucket counters behind them)
+    const size_t rsort = (((size_t)max_seg * 8 + 15) & ~(size_t)15) + (size_t)(rs_buckets(blk) + 16) * 4;
     size_t box_bytes = boxes > xch ? boxes : xch;
     if (rsort > box_bytes) box_bytes = rsort;
     l.box = off;     off += box_bytes;
@@ -922,7 +924,7 @@ __device__ inline bool nms_pairs_body(
                        (unsigned long long)(0xffffffffu - (uint32_t)i);
         }
         bool ranked = false;
-        if constexpr (BLK > 64) if (!np.network_sort) {
+        if (!np.network_sort) {
             uint32_t rk[JPT];
             uint32_t *s_hist = reinterpret_cast<uint32_t *>(lds_base + ld.box + ((((size_t)np.max_seg * 8 + 15) & ~(size_t)15)));
             ranked = rank_by_buckets<JPT, BLK>(K, n, s_keys, s_hist, rk);
