@@ -535,7 +535,7 @@ def main():
             torch.cuda.empty_cache()
             # graph replay where the host's launch rate is what binds (issuing a stage twice costs more than the
             # stage's kernels take: tools/twice.sh): the small workload and the trained-like regime
-            # sparse: the survey's second regime (+8 on the background column / -6 on the objectness).  exact: the same dense
+            # sparse: a head whose background column is raised by 8 (objectness lowered by 6): a few thousand candidates per image.  exact: the same dense
             # workload with torch's own activation instead of the fused one -- the mode whose keep lists are bit-exact.
             for name, regime, steps, graph, exact in (
                     ('ssd300', 'dense', 200, True, False), ('ssd300_b512', 'dense', 20, False, False),
