@@ -21,6 +21,7 @@ SIGNATURES = {
     'detbox_box_convert': (_i32, [_p, _p, _i64, _i32, _i32, _p]),
     'detbox_box_iou': (_i32, [_p, _i64, _p, _i64, _p, _p]),
     'detbox_assign_anchor_workspace_bytes': (_sz, [_i64]),
+    'detbox_assign_anchor_workspace_bytes_for': (_sz, [_i64, _i64, _i64]),
     'detbox_assign_anchor': (_i32, [_i32, _p, _i64, _p, _p, _p, _i64, _i64, _f32, _f32, _p, _p, _p, _p, _p, _sz, _p]),
     'detbox_assign_anchor_noalloc': (_i32, [_i32, _p, _i64, _p, _p, _p, _i64, _i64, _f32, _f32, _p, _p, _p, _p, _p]),
     'detbox_assign_fcos': (_i32, [_p, _p, _i64, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p]),

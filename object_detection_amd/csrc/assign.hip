@@ -52,7 +52,11 @@ __global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
     const float4 *__restrict__ gt_boxes, const int64_t *__restrict__ gt_labels,
     const int32_t *__restrict__ gt_off, int B, int imgs_per_block, float thr_lo, float thr_hi,
     float4 *__restrict__ locs, int64_t *__restrict__ labels, int64_t *__restrict__ matched,
-    unsigned long long *__restrict__ colbest) {
+    unsigned long long *__restrict__ colbest, unsigned long long *__restrict__ colpart) {
+    // Per-GT arg-max over the anchors: every workgroup has its own best (IoU, anchor) word per GT box of its images.  With
+    // colpart != null it stores that word, zero included, into its own column of colpart [total_gt, gridDim.x] and the
+    // relabelling kernel takes the maximum of a row: plain stores, nothing to clear beforehand.  Otherwise (callers that
+    // bring one slot per GT box only) the workgroups meet in colbest [total_gt] with one global atomicMax each.
     __shared__ float4 s_xyxy[GCHUNK];
     __shared__ float s_area[GCHUNK];
     __shared__ float2 s_xy[GCHUNK];                 // YOLO: raw GT top-left
@@ -183,7 +187,8 @@ __global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
             __syncthreads();
             if (tid < gc) {
                 const unsigned long long k = s_col[tid];
-                if (k != 0ull) atomicMax(&colbest[g0 + c0 + tid], k);
+                if (colpart) colpart[(size_t)(g0 + c0 + tid) * gridDim.x + blockIdx.x] = k;
+                else if (k != 0ull) atomicMax(&colbest[g0 + c0 + tid], k);
             }
         }
         // the last chunk is still in LDS (the only one unless an image has more than GCHUNK boxes)
@@ -217,10 +222,12 @@ __global__ __launch_bounds__(ASSIGN_BLOCK) void assign_anchor_kernel(
 // of its own arg-max GT: the reference's "assign GT j" loop writes into a
 // temporary (ssd300.py:256-257).
 __global__ __launch_bounds__(256) void assign_fixup_kernel(
-    const unsigned long long *__restrict__ colbest, const int32_t *__restrict__ gt_off, int B, int total_gt, int P,
+    const unsigned long long *__restrict__ colbest, const unsigned long long *__restrict__ colpart, int nwg,
+    const int32_t *__restrict__ gt_off, int B, int total_gt, int P,
     const int64_t *__restrict__ gt_labels, const int64_t *__restrict__ matched, float thr_lo, float thr_hi,
     int64_t *__restrict__ labels, int64_t *__restrict__ best_anchor) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    // with the per-workgroup table: one wave per GT box (the row's words are spread over the lanes); else one thread
+    const int t = colpart ? (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (t >= total_gt) return;
     int lo = 0, hi = B;                      // largest b with gt_off[b] <= t
     while (hi - lo > 1) {
@@ -228,7 +235,19 @@ __global__ __launch_bounds__(256) void assign_fixup_kernel(
         if (gt_off[mid] <= t) lo = mid; else hi = mid;
     }
     const int b = lo;
-    const unsigned long long k = colbest[t];
+    unsigned long long k = 0ull;
+    if (colpart) {                           // the best word over the assignment's workgroups (a row of colpart)
+        const unsigned long long *row = colpart + (size_t)t * nwg;
+        for (int w = (int)(threadIdx.x & 63); w < nwg; w += 64) { const unsigned long long v = row[w]; k = v > k ? v : k; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long v = ((unsigned long long)(unsigned)__shfl_xor((int)(k >> 32), o) << 32) | (unsigned)__shfl_xor((int)k, o);
+            k = v > k ? v : k;
+        }
+        if ((threadIdx.x & 63) != 0) return;
+    } else {
+        k = colbest[t];
+    }
     const unsigned pbest = (k == 0ull) ? 0u : (0xffffffffu - (unsigned)(k & 0xffffffffull));
     if (best_anchor) best_anchor[t] = (int64_t)pbest;
     const size_t o = (size_t)b * P + pbest;
@@ -314,17 +333,35 @@ extern "C" size_t detbox_assign_anchor_workspace_bytes(int64_t total_gt) {
 }
 
 namespace {
+// four anchors per thread once that still leaves about four workgroups per CU (33 against 44 us on 16 x 120087 anchors)
+int assign_apt(int64_t P, int64_t B) { return (P * B >= (int64_t)4 * ASSIGN_BLOCK * 1024) ? 4 : 1; }
+int64_t assign_tiles(int64_t P, int64_t B) { const int apt = assign_apt(P, B); return (P + ASSIGN_BLOCK * apt - 1) / (ASSIGN_BLOCK * apt); }
+// bytes of the [total_gt, workgroups] table of per-workgroup arg-max words
+size_t assign_part_bytes(int64_t total_gt, int64_t P, int64_t B) {
+    return align_up((size_t)(total_gt < 0 ? 0 : total_gt) * (size_t)assign_tiles(P, B) * sizeof(unsigned long long) + 256, 256);
+}
+constexpr size_t ASSIGN_PART_MAX_BYTES = (size_t)256 << 20;       // beyond this the one-slot-per-GT form is asked for
+}  // namespace
 
-// Shared by the two entry points: `colbest` holds one 64-bit slot per GT box (cleared here, on the stream).
+extern "C" size_t detbox_assign_anchor_workspace_bytes_for(int64_t total_gt, int64_t P, int64_t B) {
+    const size_t one = detbox_assign_anchor_workspace_bytes(total_gt);
+    if (P <= 0 || B <= 0) return one;
+    const size_t part = assign_part_bytes(total_gt, P, B);
+    return part <= ASSIGN_PART_MAX_BYTES && part > one ? part : one;
+}
+
+namespace {
+
+// Shared by the two entry points.  Either `colpart` holds one 64-bit word per (GT box, workgroup of the assignment) --
+// written whole by the assignment, nothing to clear -- or `colbest` holds one slot per GT box (cleared here, on the stream).
 int assign_anchor_run(int mode, const float *anchors, int64_t P,
                       const float *gt_boxes, const int64_t *gt_labels, const int32_t *gt_offsets,
                       int64_t B, int64_t total_gt, float thr_lo, float thr_hi,
                       float *target_locs, int64_t *target_labels, int64_t *matched,
-                      int64_t *best_anchor, unsigned long long *colbest, hipStream_t s) {
-    if (total_gt > 0) DETBOX_HIP(hipMemsetAsync(colbest, 0, (size_t)total_gt * sizeof(unsigned long long), s));
-    // four anchors per thread once that still leaves about four workgroups per CU (33 against 44 us on 16 x 120087 anchors)
-    const int apt = (P * B >= (int64_t)4 * ASSIGN_BLOCK * 1024) ? 4 : 1;
-    const int64_t tiles = (P + ASSIGN_BLOCK * apt - 1) / (ASSIGN_BLOCK * apt);
+                      int64_t *best_anchor, unsigned long long *colbest, unsigned long long *colpart, hipStream_t s) {
+    if (total_gt > 0 && !colpart) DETBOX_HIP(hipMemsetAsync(colbest, 0, (size_t)total_gt * sizeof(unsigned long long), s));
+    const int apt = assign_apt(P, B);
+    const int64_t tiles = assign_tiles(P, B);
     const int ipb = pick_imgs_per_block(tiles, B);
     dim3 grid((unsigned)tiles, (unsigned)((B + ipb - 1) / ipb));
     {
@@ -332,7 +369,7 @@ int assign_anchor_run(int mode, const float *anchors, int64_t P,
 #define DETBOX_ASSIGN(MODE, APT)                                                                                   \
     assign_anchor_kernel<MODE, APT><<<grid, dim3(ASSIGN_BLOCK), 0, s>>>(                                           \
         anchors, (int)P, reinterpret_cast<const float4 *>(gt_boxes), gt_labels, gt_offsets, (int)B, ipb, thr_lo,   \
-        thr_hi, reinterpret_cast<float4 *>(target_locs), target_labels, matched, colbest)
+        thr_hi, reinterpret_cast<float4 *>(target_locs), target_labels, matched, colbest, colpart)
         if (mode == DETBOX_ASSIGN_CXCYWH) { if (apt == 4) DETBOX_ASSIGN(DETBOX_ASSIGN_CXCYWH, 4); else DETBOX_ASSIGN(DETBOX_ASSIGN_CXCYWH, 1); }
         else { if (apt == 4) DETBOX_ASSIGN(DETBOX_ASSIGN_YOLO, 4); else DETBOX_ASSIGN(DETBOX_ASSIGN_YOLO, 1); }
 #undef DETBOX_ASSIGN
@@ -340,9 +377,10 @@ int assign_anchor_run(int mode, const float *anchors, int64_t P,
     }
     if (total_gt > 0) {
         ProfScope ps("assign_fixup", s);
-        assign_fixup_kernel<<<dim3((unsigned)((total_gt + 255) / 256)), dim3(256), 0, s>>>(
-            colbest, gt_offsets, (int)B, (int)total_gt, (int)P, gt_labels, matched, thr_lo, thr_hi, target_labels,
-            best_anchor);
+        // (table form: a wave per GT box, four to a workgroup)
+        assign_fixup_kernel<<<dim3((unsigned)(colpart ? (total_gt + 3) / 4 : (total_gt + 255) / 256)), dim3(256), 0, s>>>(
+            colbest, colpart, (int)tiles, gt_offsets, (int)B, (int)total_gt, (int)P, gt_labels, matched, thr_lo, thr_hi,
+            target_labels, best_anchor);
         DETBOX_LAUNCH_CHECK();
     }
     return DETBOX_OK;
@@ -377,8 +415,11 @@ extern "C" int detbox_assign_anchor(int mode, const float *anchors, int64_t P,
                   detbox_assign_anchor_workspace_bytes(total_gt));
         return DETBOX_ERR_WORKSPACE;
     }
+    // a workspace of detbox_assign_anchor_workspace_bytes_for(...) bytes holds the per-workgroup table; a smaller one the slots
+    unsigned long long *ws = static_cast<unsigned long long *>(workspace);
+    const bool table = workspace_bytes >= assign_part_bytes(total_gt, P, B) && assign_part_bytes(total_gt, P, B) <= ASSIGN_PART_MAX_BYTES;
     return assign_anchor_run(mode, anchors, P, gt_boxes, gt_labels, gt_offsets, B, total_gt, thr_lo, thr_hi, target_locs,
-                             target_labels, matched, best_anchor, static_cast<unsigned long long *>(workspace),
+                             target_labels, matched, best_anchor, table ? nullptr : ws, table ? ws : nullptr,
                              static_cast<hipStream_t>(stream));
 }
 
@@ -429,7 +470,7 @@ extern "C" int detbox_assign_anchor_noalloc(int mode, const float *anchors, int6
     if (int rc = scratch_of_current_device(&colbest)) return rc;
     // assign_anchor_run clears the slots it uses on the stream before the kernels: the array keeps the last call's contents
     return assign_anchor_run(mode, anchors, P, gt_boxes, gt_labels, gt_offsets, B, total_gt, thr_lo, thr_hi, target_locs,
-                             target_labels, matched, best_anchor, colbest, static_cast<hipStream_t>(stream));
+                             target_labels, matched, best_anchor, colbest, nullptr, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int detbox_assign_fcos(const float *points, const float *regress_ranges, int64_t P,

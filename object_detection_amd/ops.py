@@ -224,7 +224,7 @@ def assign_anchor(anchors: torch.Tensor, gt_boxes: torch.Tensor, gt_labels: torc
     L = _lib.lib()
     with _on(dev):
         st = _stream(dev)
-        ws = _workspace(dev, _ws_bytes(dev, L.detbox_assign_anchor_workspace_bytes, total_gt), 'assign', st)
+        ws = _workspace(dev, _ws_bytes(dev, L.detbox_assign_anchor_workspace_bytes_for, total_gt, P, B), 'assign', st)
         _lib.check(L.detbox_assign_anchor(mode, _ptr(anchors), P, _ptr(gt_boxes), _ptr(gt_labels), _ptr(gt_offsets),
                                           B, total_gt, thr_lo, thr_hi, _ptr(locs), _ptr(labels), _ptr(matched),
                                           _ptr(best), ws.data_ptr(), ws.numel(), st), 'detbox_assign_anchor')

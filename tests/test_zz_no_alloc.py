@@ -42,6 +42,18 @@ def _both(D, dev, anchors, gb, gl, mode, lo, hi, first=False):
     wl, wlab, wm, wbest = want
     assert torch.equal(labels, wlab) and torch.equal(matched, wm) and torch.equal(best[:total], wbest)
     assert torch.equal(locs, wl)                 # the same kernels on the same inputs: identical bits
+    # the workspace entry point with the small workspace (one slot per GT box: the atomic form of the per-GT arg-max; `want`
+    # above came from the larger one, where every workgroup stores its own word and nothing is cleared)
+    small = L.detbox_assign_anchor_workspace_bytes(total)
+    assert small <= L.detbox_assign_anchor_workspace_bytes_for(total, P, B)
+    ws = torch.full((small,), 0xA5, dtype=torch.uint8, device=dev)
+    locs2, labels2, matched2, best2 = torch.empty_like(locs), torch.empty_like(labels), torch.empty_like(matched), torch.empty_like(best)
+    rc = L.detbox_assign_anchor(mode, anchors.data_ptr(), P, gbp.data_ptr(), glp.data_ptr(), off.data_ptr(), B, total, lo, hi,
+                                locs2.data_ptr(), labels2.data_ptr(), matched2.data_ptr(), best2.data_ptr(), ws.data_ptr(), small,
+                                torch.cuda.current_stream(dev).cuda_stream)
+    D.ops._lib.check(rc, 'detbox_assign_anchor')
+    torch.cuda.synchronize()
+    assert torch.equal(labels2, wlab) and torch.equal(matched2, wm) and torch.equal(best2[:total], wbest) and torch.equal(locs2, wl)
     return total
 
 
