@@ -83,8 +83,7 @@ int detbox_box_iou(const float *boxes1, int64_t n, const float *boxes2, int64_t 
  * An image with no GT gets labels 0, matched -1 and zero offsets (the reference raises). */
 size_t detbox_assign_anchor_workspace_bytes(int64_t total_gt);
 /* The larger workspace with which detbox_assign_anchor does without global atomics: one word per (GT box, workgroup of
- * the assignment) that the workgroups store and the relabelling step reduces (nothing to clear beforehand; 27 -> 17 us on
- * 16 x 120087 anchors).  Never smaller than detbox_assign_anchor_workspace_bytes(total_gt), which detbox_assign_anchor
+ * the assignment) that the workgroups store and the relabelling step reduces (nothing to clear beforehand: one launch less per call).  Never smaller than detbox_assign_anchor_workspace_bytes(total_gt), which detbox_assign_anchor
  * accepts as well (it then meets in one slot per GT box with an atomic per workgroup).  No counterpart in the reference. */
 size_t detbox_assign_anchor_workspace_bytes_for(int64_t total_gt, int64_t P, int64_t B);
 int detbox_assign_anchor(int mode, const float *anchors, int64_t P,
